@@ -1,0 +1,83 @@
+"""ctypes binding of libcogaim.so (the C ABI declared in include/cogaim.h).
+
+The library is mandatory: there is no eager / CPU fallback.  ``lib()`` raises
+if it has not been built (``python -m cognitive_aim_depth_estimation_amd.build``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcogaim.so")
+
+P, I, F, LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+# name -> argument types (all return int); mirrors include/cogaim.h
+SIGNATURES = {
+    "cogaim_version": [],
+    "cogaim_im2col": [P, P, I, I, I, I, I, I, P],
+    "cogaim_gemm_patch_embed": [P, P, P, P, P, I, I, I, I, I, P],
+    "cogaim_cls_row": [P, P, P, I, I, I, P],
+    "cogaim_layernorm": [P, P, P, P, I, I, F, I, P],
+    "cogaim_gemm_bias_half": [P, P, P, P, I, I, I, I, I, I, I, F, I, P],
+    "cogaim_gemm_vt": [P, P, P, P, I, I, I, I, I, I, I, I, P],
+    "cogaim_mhsa_fwd": [P, P, P, I, I, I, I, I, I, P],
+    "cogaim_gemm_residual_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "cogaim_gemm_bias_gelu_half": [P, P, P, P, I, I, I, I, I, I, I, P],
+    "cogaim_focal_prep": [P, LL, P, P, P, I, I, I, I, P],
+    "cogaim_gemm_batched_f32": [P, P, P, I, I, I, I, I, I, LL, LL, LL, I, I, P],
+    "cogaim_focal_colsum_rows": [],
+    "cogaim_focal_softmax_stats_colsum": [P, I, LL, P, P, P, I, I, P],
+    "cogaim_focal_attention_vector": [P, P, P, P, P, P, F, I, I, P],
+    "cogaim_focal_var_flag": [P, I, I, P, I, P],
+    "cogaim_focal_weighted_colsum": [P, I, LL, P, P, P, P, I, I, P],
+    "cogaim_focal_reduce_u": [P, P, P, I, I, P],
+    "cogaim_weighted_tokens": [P, LL, P, P, P, P, I, I, I, P],
+    "cogaim_guided_attention": [P, P, P, I, I, F, F, P],
+    "cogaim_linear_f32": [P, I, P, P, P, P, I, I, I, I, I, P],
+    "cogaim_exif_prep": [P, P, P, P, P, I, P, I, P, I, P],
+    "cogaim_heads": [P, I, P, P, P, P, P, P, P, P, I, P],
+}
+
+_NO_STATUS = {"cogaim_version", "cogaim_focal_colsum_rows"}
+_lib = None
+
+
+class CogaimError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CogaimError(
+                f"{LIB_PATH} is missing: build it with "
+                "`python -m cognitive_aim_depth_estimation_amd.build` (hipcc, gfx950). "
+                "This package has no CPU or eager fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = args
+            fn.restype = I
+        _lib = handle
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    rc = getattr(lib(), name)(*args)
+    if name not in _NO_STATUS and rc != 0:
+        raise CogaimError(f"{name} failed with code {rc}")
+    return rc

@@ -1,0 +1,205 @@
+// Fused multi-head self-attention (flash style) for the DINOv2 blocks on gfx950.
+// Head dim is fixed at 64.  Computes ctx = softmax(Q K^T) V per (image, head)
+// with the score matrix never leaving registers.
+//
+// Layout choices (all for the 64-lane v_mfma_f32_32x32x16 fragment maps):
+//  * scores are produced TRANSPOSED, S^T = K Q^T, so a lane owns one query
+//    column: the running max / sum / rescale factors are lane-local scalars
+//    and the only cross-lane step per tile is one v_permlane32_swap;
+//  * the S^T accumulator (rows = keys) is converted to 16-bit in place and fed
+//    straight back as the B operand of O^T += V^T P^T (no LDS round trip);
+//  * V arrives pre-transposed per head ([d][token], written that way by the
+//    QKV GEMM epilogue) so the A operand of that product is key-contiguous.
+// Q is expected pre-multiplied by dh^-0.5 * log2(e): softmax runs on exp2.
+#include "common.h"
+
+namespace {
+
+constexpr int KV = 64;            // keys per tile
+constexpr int QB = 128;           // queries per block (4 waves x 32)
+constexpr int K_TILE = KV * 128;  // K tile: 64 keys x 64 d x 2 B, chunk-swizzled
+constexpr int V_ROW = 136;        // V^T tile row stride in bytes (64 keys + 8 B pad: conflict-free ds_read_b64)
+constexpr int V_TILE = 64 * V_ROW;
+
+template <class T>
+__global__ __launch_bounds__(256, 2) void mhsa_kernel(const T* __restrict__ qk, const T* __restrict__ vt,
+                                                   T* __restrict__ ctx, int Tn, int H, int Tp, int ldqk, int D) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE + 2 * V_TILE];
+  using Hf = Half<T>;
+  using v8 = typename Hf::v8;
+  typedef T v4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, hh = lane >> 5;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int q0 = blockIdx.x * QB + wave * 32;
+  const size_t row0 = (size_t)b * Tn;
+
+  // Q fragments: B operand, lane (q = ql, half hh) holds Q[q][16 s + 8 hh .. +7]
+  v8 qf[4];
+  {
+    int q = q0 + ql; q = q < Tn ? q : Tn - 1;
+    const T* qp = qk + (row0 + q) * ldqk + h * 64 + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const v8*>(qp + 16 * s);
+  }
+
+  // staging assignment: thread handles 16-B chunks idx = tid and tid + 256 of each tile
+  const T* kbase = qk + D + h * 64;
+  const T* vbase = vt + (size_t)bh * 64 * Tp;
+  // (explicit scalars, not arrays: arrays captured by the staging code end up in scratch)
+  uint4 kreg0, kreg1;
+  uint2 vreg0a, vreg0b, vreg1a, vreg1b;
+  const int sr0 = tid >> 3, sr1 = sr0 + 32, sc = tid & 7;
+#define LOAD_TILE(kv0_)                                                                          \
+  {                                                                                              \
+    int key0 = (kv0_) + sr0; key0 = key0 < Tn ? key0 : Tn - 1;                                   \
+    int key1 = (kv0_) + sr1; key1 = key1 < Tn ? key1 : Tn - 1;                                   \
+    kreg0 = *reinterpret_cast<const uint4*>(kbase + (row0 + key0) * ldqk + sc * 8);              \
+    kreg1 = *reinterpret_cast<const uint4*>(kbase + (row0 + key1) * ldqk + sc * 8);              \
+    const uint2* v0 = reinterpret_cast<const uint2*>(vbase + (size_t)sr0 * Tp + (kv0_) + sc * 8); \
+    const uint2* v1 = reinterpret_cast<const uint2*>(vbase + (size_t)sr1 * Tp + (kv0_) + sc * 8); \
+    vreg0a = v0[0]; vreg0b = v0[1]; vreg1a = v1[0]; vreg1b = v1[1];                              \
+  }
+#define STORE_TILE(buf_)                                                                         \
+  {                                                                                              \
+    char* ks_ = smem + (buf_) * K_TILE;                                                          \
+    char* vs_ = smem + 2 * K_TILE + (buf_) * V_TILE;                                             \
+    *reinterpret_cast<uint4*>(ks_ + sr0 * 128 + ((sc ^ ((sr0 >> 1) & 7)) << 4)) = kreg0;         \
+    *reinterpret_cast<uint4*>(ks_ + sr1 * 128 + ((sc ^ ((sr1 >> 1) & 7)) << 4)) = kreg1;         \
+    uint2* p0 = reinterpret_cast<uint2*>(vs_ + sr0 * V_ROW + sc * 16);                           \
+    uint2* p1 = reinterpret_cast<uint2*>(vs_ + sr1 * V_ROW + sc * 16);                           \
+    p0[0] = vreg0a; p0[1] = vreg0b; p1[0] = vreg1a; p1[1] = vreg1b;                              \
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nt = (Tn + KV - 1) / KV;
+  LOAD_TILE(0);
+  STORE_TILE(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int kv0 = t * KV;
+    if (t + 1 < nt) LOAD_TILE(kv0 + KV);
+    const char* ks = smem + (t & 1) * K_TILE;
+    const char* vs = smem + 2 * K_TILE + (t & 1) * V_TILE;
+
+    // S^T = K Q^T : s[kb][i] = S^T[key kb*32 + (i&3) + 8(i>>2) + 4hh][query ql]
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+      const int r = kb * 32 + ql;
+      const int sw = (r >> 1) & 7;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const v8 kf = *reinterpret_cast<const v8*>(ks + r * 128 + (((2 * s4 + hh) ^ sw) << 4));
+        s[kb] = Hf::mfma32(kf, qf[s4], s[kb]);
+      }
+    }
+    if (kv0 + KV > Tn) {   // mask keys past the sequence end (last tile only)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (key >= Tn) s[kb][i] = -INFINITY;
+        }
+    }
+    // online softmax, per query column (lane-local + one half swap)
+    float mx = s[0][0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
+    {
+      const unsigned u = __float_as_uint(mx);
+      auto sw2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+      mx = fmaxf(__uint_as_float(sw2[0]), __uint_as_float(sw2[1]));
+    }
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float lsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s[kb][i] = __builtin_amdgcn_exp2f(s[kb][i] - m_new);
+        lsum += s[kb][i];
+      }
+    l_run = l_run * alpha + lsum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+
+    // O^T += V^T P^T : A = V^T fragment (rows = d), B = P^T fragment (the S^T registers)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        v8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (T)s[kb][8 * ks2 + j];
+        const int key = kb * 32 + 16 * ks2 + 4 * hh;   // element j -> key + 8(j>>2) + (j&3)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const char* vp = vs + (dt * 32 + ql) * V_ROW + key * 2;
+          const v4 lo = *reinterpret_cast<const v4*>(vp);
+          const v4 hi = *reinterpret_cast<const v4*>(vp + 16);
+          o[dt] = Hf::mfma32(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), pf, o[dt]);
+        }
+      }
+
+    if (t + 1 < nt) STORE_TILE((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // combine the two lane halves' partial sums, normalise, store ctx[b*T+q][h*64 + d]
+  {
+    const unsigned u = __float_as_uint(l_run);
+    auto sw2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    l_run = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
+  }
+  const float inv = 1.0f / l_run;
+  const int q = q0 + ql;
+  if (q < Tn) {
+    T* op = ctx + (row0 + q) * D + h * 64 + 4 * hh;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<Half4<T>*>(op + dt * 32 + 8 * g) =
+            to_half4<T>(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+  }
+}
+
+#undef LOAD_TILE
+#undef STORE_TILE
+
+}  // namespace
+
+extern "C" {
+
+// qk: [B*T, ldqk] 16-bit, Q (pre-scaled by 64^-0.5 * log2 e) in columns [0,D), K in [D,2D);
+// vt: [B*H, 64, Tp] 16-bit (Tp multiple of 64, >= T; columns past T may hold anything finite);
+// ctx: [B*T, D] 16-bit.  D = 64*H.
+int cogaim_mhsa_fwd(const void* qk, const void* vt, void* ctx, int B, int T, int H, int Tp, int ldqk, int dtype,
+                    void* stream) {
+  if (B <= 0 || T <= 0 || H <= 0 || (Tp & 63) || Tp < T || (ldqk & 7)) return COGAIM_EINVAL;
+  const int D = 64 * H;
+  dim3 grid((T + QB - 1) / QB, B * H);
+  if (dtype == 0)
+    hipLaunchKernelGGL(mhsa_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)qk,
+                       (const __bf16*)vt, (__bf16*)ctx, T, H, Tp, ldqk, D);
+  else if (dtype == 1)
+    hipLaunchKernelGGL(mhsa_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)qk,
+                       (const _Float16*)vt, (_Float16*)ctx, T, H, Tp, ldqk, D);
+  else
+    return COGAIM_EINVAL;
+  return COGAIM_LAUNCH_CHECK();
+}
+
+}  // extern "C"

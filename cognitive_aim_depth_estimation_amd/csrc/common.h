@@ -1,0 +1,78 @@
+// Shared device helpers for the gfx950 (MI355X) kernels of the Cognitive-Aim
+// depth forward pass.  Wave size is 64 everywhere in this library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define COGAIM_OK 0
+#define COGAIM_EINVAL (-22)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 16-bit operand traits: bf16 (dtype 0) and fp16 (dtype 1) share every kernel.
+template <class T> struct Half;
+template <> struct Half<__bf16> {
+  using v8 = bf16x8;
+  static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Half<_Float16> {
+  using v8 = f16x8;
+  static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <class T> struct alignas(8) Half4 { T v[4]; };
+
+template <class T>
+__device__ __forceinline__ Half4<T> to_half4(float a, float b, float c, float d) {
+  Half4<T> r;
+  r.v[0] = (T)a; r.v[1] = (T)b; r.v[2] = (T)c; r.v[3] = (T)d;
+  return r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Sum over a 256-thread block; result valid in every thread.  `red` is 4+ floats of LDS.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+static inline int hip_rc(hipError_t e) { return e == hipSuccess ? COGAIM_OK : -1000 - (int)e; }
+#define COGAIM_LAUNCH_CHECK() hip_rc(hipGetLastError())

@@ -1,0 +1,280 @@
+// Focal-stream kernels (reference src/model.py:128-313, 391-455) for gfx950.
+//
+// One FocalStream call is evaluated as
+//   Xt   = tokens * scale + pe                               (focal_prep, 16-bit GEMM operand)
+//   Q,K  = Xt Wq^T + bq, Xt Wk^T + bk                        (MFMA GEMM, gemm.hip)
+//   S    = Q K^T / sqrt(D/8) * log2(e)                       (batched MFMA GEMM, fp32 scores)
+//   m,l  = row max / row sum of exp2(S - m)                  (focal_colsum<STATS>)
+//   c    = column mean of P = exp2(S - m) / l                (same kernel + attention_vector)
+//   a    = renorm(clamp(renorm(c + centre bias)))            (focal_attention_vector)
+//   u    = a^T P                                             (focal_colsum<weighted>)
+//   w    = (u^T Xt) Wv^T + (sum u) bv                        (focal_weighted_tokens + small linears)
+// The last two lines use sum_n a_n (P V)_n = (a^T P) V, so the N x N x D product
+// P V and the V projection of every token are never formed.
+#include "common.h"
+
+namespace {
+
+template <class T>
+__global__ __launch_bounds__(256) void focal_prep_kernel(const float* __restrict__ tok, long long tok_stride_b,
+                                                         const float* __restrict__ scale, const float* __restrict__ pe,
+                                                         T* __restrict__ out, int B, int N, int D) {
+  const int dv = D >> 2;
+  const long long total = (long long)B * N * dv;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % dv);
+    const long long row = i / dv;
+    const int n = (int)(row % N), b = (int)(row / N);
+    const float4 x = reinterpret_cast<const float4*>(tok + b * tok_stride_b + (size_t)n * D)[c];
+    const float4 p = reinterpret_cast<const float4*>(pe + (size_t)n * D)[c];
+    const float s = scale ? scale[row] : 1.0f;
+    reinterpret_cast<Half4<T>*>(out + row * D)[c] =
+        to_half4<T>(x.x * s + p.x, x.y * s + p.y, x.z * s + p.z, x.w * s + p.w);
+  }
+}
+
+constexpr int CS_ROWS = 32;   // score rows per block
+
+// part[b][blk][c] = sum over the block's rows n of w_n * exp2(S[n][c] - m_n) * inv_n
+// STATS: m_n, inv_n are computed here (and stored); w_n = 1.   else: read m, inv; w_n = roww[b][n].
+template <bool STATS>
+__global__ __launch_bounds__(256) void focal_colsum_kernel(const float* __restrict__ S, int ldS, long long strideS,
+                                                           float* __restrict__ rmax, float* __restrict__ rinv,
+                                                           const float* __restrict__ roww, float* __restrict__ part,
+                                                           int N, int nblk) {
+  __shared__ float m_s[CS_ROWS], i_s[CS_ROWS];
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blk * CS_ROWS;
+  const float* Sb = S + b * strideS;
+  if constexpr (STATS) {
+    for (int rr = wave; rr < CS_ROWS; rr += 4) {
+      const int row = r0 + rr;
+      if (row < N) {
+        const float* sr = Sb + (size_t)row * ldS;
+        float mx = -INFINITY;
+        for (int c = lane; c < N; c += 64) mx = fmaxf(mx, sr[c]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int c = lane; c < N; c += 64) sum += __builtin_amdgcn_exp2f(sr[c] - mx);
+        sum = wave_sum(sum);
+        if (lane == 0) {
+          m_s[rr] = mx; i_s[rr] = 1.0f / sum;
+          rmax[(size_t)b * N + row] = mx; rinv[(size_t)b * N + row] = 1.0f / sum;
+        }
+      } else if (lane == 0) { m_s[rr] = 0.f; i_s[rr] = 0.f; }
+    }
+  } else {
+    if (tid < CS_ROWS) {
+      const int row = r0 + tid;
+      const bool ok = row < N;
+      m_s[tid] = ok ? rmax[(size_t)b * N + row] : 0.f;
+      i_s[tid] = ok ? rinv[(size_t)b * N + row] * roww[(size_t)b * N + row] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int rows = min(CS_ROWS, N - r0);
+  for (int c = tid; c < N; c += 256) {
+    float acc = 0.f;
+    for (int rr = 0; rr < rows; ++rr)
+      acc += __builtin_amdgcn_exp2f(Sb[(size_t)(r0 + rr) * ldS + c] - m_s[rr]) * i_s[rr];
+    part[((size_t)b * nblk + blk) * N + c] = acc;
+  }
+}
+
+// per image: a = renorm(clamp(renorm(colmean + centre_bias)));  model.py:234-282
+__global__ __launch_bounds__(256) void focal_attention_vector_kernel(const float* __restrict__ part, int nblk,
+                                                                     const float* __restrict__ cbias,
+                                                                     float* __restrict__ a, double* __restrict__ stats,
+                                                                     const float* __restrict__ scale_in,
+                                                                     float* __restrict__ scale_out, float focus_strength,
+                                                                     int N) {
+  __shared__ float red[4];
+  __shared__ double redd[8];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float* ab = a + (size_t)b * N;
+  float s1 = 0.f; double d1 = 0.0, d2 = 0.0;
+  const float invN = 1.0f / (float)N;
+  for (int c = tid; c < N; c += 256) {
+    float cs = 0.f;
+    for (int k = 0; k < nblk; ++k) cs += part[((size_t)b * nblk + k) * N + c];
+    const float pa = cs * invN + cbias[c];
+    ab[c] = pa; s1 += pa; d1 += pa; d2 += (double)pa * pa;
+  }
+  const float t1 = block_sum_256(s1, red);
+  d1 = wave_sum_d(d1); d2 = wave_sum_d(d2);
+  if ((tid & 63) == 0) { redd[tid >> 6] = d1; redd[4 + (tid >> 6)] = d2; }
+  __syncthreads();
+  if (tid == 0) {
+    stats[2 * b] = redd[0] + redd[1] + redd[2] + redd[3];
+    stats[2 * b + 1] = redd[4] + redd[5] + redd[6] + redd[7];
+  }
+  const float d = t1 + 1e-8f;
+  float s2 = 0.f;
+  for (int c = tid; c < N; c += 256) {
+    const float v = fmaxf(ab[c] / d, 1e-8f);
+    ab[c] = v; s2 += v;
+  }
+  const float t2 = block_sum_256(s2, red) + 1e-8f;
+  for (int c = tid; c < N; c += 256) {
+    const float v = ab[c] / t2;
+    ab[c] = v;
+    if (scale_out) scale_out[(size_t)b * N + c] = (scale_in ? scale_in[(size_t)b * N + c] : 1.0f) * (1.0f + focus_strength * v);
+  }
+}
+
+// whole-batch unbiased variance of (colmean + bias) < 1e-6  ->  flags[slot] = 1   (model.py:242)
+__global__ void focal_var_flag_kernel(const double* __restrict__ stats, int B, int N, int* __restrict__ flags, int slot) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < B; ++b) { s += stats[2 * b]; q += stats[2 * b + 1]; }
+  const double n = (double)B * N;
+  const double var = (q - s * s / n) / (n - 1.0);
+  flags[slot] = (var < 1e-6) ? 1 : 0;
+}
+
+// u[b][c] = sum_blk part[b][blk][c];  usum[b] = sum_c u[b][c]
+__global__ __launch_bounds__(256) void focal_reduce_u_kernel(const float* __restrict__ part, int nblk,
+                                                             float* __restrict__ u, float* __restrict__ usum, int N) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f;
+  for (int c = tid; c < N; c += 256) {
+    float cs = 0.f;
+    for (int k = 0; k < nblk; ++k) cs += part[((size_t)b * nblk + k) * N + c];
+    u[(size_t)b * N + c] = cs; s += cs;
+  }
+  const float t = block_sum_256(s, red);
+  if (tid == 0) usum[b] = t;
+}
+
+// out[b][d] = sum_n w[b][n] * (tok[b][n][d] * scale[b][n] + pe[n][d])     (scale, pe optional)
+__global__ __launch_bounds__(256) void focal_weighted_tokens_kernel(const float* __restrict__ tok,
+                                                                    long long tok_stride_b,
+                                                                    const float* __restrict__ scale,
+                                                                    const float* __restrict__ pe,
+                                                                    const float* __restrict__ w, float* __restrict__ out,
+                                                                    int N, int D) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int col = blockIdx.x * 64 + (tid & 63), rg = tid >> 6;
+  float acc = 0.f;
+  if (col < D) {
+    const float* tb = tok + b * tok_stride_b;
+    for (int n = rg; n < N; n += 4) {
+      float x = tb[(size_t)n * D + col];
+      if (scale) x *= scale[(size_t)b * N + n];
+      if (pe) x += pe[(size_t)n * D + col];
+      acc += w[(size_t)b * N + n] * x;
+    }
+  }
+  red[rg][tid & 63] = acc;
+  __syncthreads();
+  if (rg == 0 && col < D) out[(size_t)b * D + col] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// guided[b][c] = softmax_c((0.7 mask[c] + 0.3 a[b][c]) / 0.05)     (model.py:1401-1409)
+__global__ __launch_bounds__(256) void guided_attention_kernel(const float* __restrict__ a, const float* __restrict__ mask,
+                                                               float* __restrict__ out, int N, float alpha, float inv_temp) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* ab = a + (size_t)b * N;
+  float* ob = out + (size_t)b * N;
+  float mx = -INFINITY;
+  for (int c = tid; c < N; c += 256) {
+    const float v = (alpha * mask[c] + (1.0f - alpha) * ab[c]) * inv_temp;
+    ob[c] = v; mx = fmaxf(mx, v);
+  }
+  mx = block_max_256(mx, red);
+  float s = 0.f;
+  for (int c = tid; c < N; c += 256) { const float e = expf(ob[c] - mx); ob[c] = e; s += e; }
+  const float t = block_sum_256(s, red);
+  for (int c = tid; c < N; c += 256) ob[c] = ob[c] / t;
+}
+
+int grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int cogaim_focal_colsum_rows() { return CS_ROWS; }
+
+// out16[b*N+n][:] = tok[b][n][:] * scale[b][n] + pe[n][:]    (tok rows are D apart, images tok_stride_b apart)
+int cogaim_focal_prep(const float* tok, long long tok_stride_b, const float* scale, const float* pe, void* out, int B,
+                      int N, int D, int dtype, void* stream) {
+  if (B <= 0 || N <= 0 || (D & 3)) return COGAIM_EINVAL;
+  const int g = grid_for((long long)B * N * (D >> 2));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL(focal_prep_kernel<__bf16>, dim3(g), dim3(256), 0, st, tok, tok_stride_b, scale, pe, (__bf16*)out, B, N, D);
+  else if (dtype == 1) hipLaunchKernelGGL(focal_prep_kernel<_Float16>, dim3(g), dim3(256), 0, st, tok, tok_stride_b, scale, pe, (_Float16*)out, B, N, D);
+  else return COGAIM_EINVAL;
+  return COGAIM_LAUNCH_CHECK();
+}
+
+// Row statistics of the log2-domain scores + per-row-block column sums of the softmax.
+// part: [B][nblk][N] with nblk = ceil(N / cogaim_focal_colsum_rows()).
+int cogaim_focal_softmax_stats_colsum(const float* S, int ldS, long long strideS, float* rmax, float* rinv, float* part,
+                                      int B, int N, void* stream) {
+  if (B <= 0 || N <= 0 || ldS < N) return COGAIM_EINVAL;
+  const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
+  hipLaunchKernelGGL(focal_colsum_kernel<true>, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, S, ldS, strideS, rmax,
+                     rinv, (const float*)nullptr, part, N, nblk);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+// part[b][blk][c] = sum_{n in blk} roww[b][n] * P[b][n][c]
+int cogaim_focal_weighted_colsum(const float* S, int ldS, long long strideS, const float* rmax, const float* rinv,
+                                 const float* roww, float* part, int B, int N, void* stream) {
+  if (B <= 0 || N <= 0 || ldS < N) return COGAIM_EINVAL;
+  const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
+  hipLaunchKernelGGL(focal_colsum_kernel<false>, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, S, ldS, strideS,
+                     (float*)rmax, (float*)rinv, roww, part, N, nblk);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+// a[b][:] from column-sum partials; stats[b] = {sum, sum of squares} of (colmean + bias) in fp64;
+// scale_out = scale_in * (1 + focus_strength * a) when scale_out != NULL (scale_in NULL = ones).
+int cogaim_focal_attention_vector(const float* part, const float* center_bias, float* a, double* stats,
+                                  const float* scale_in, float* scale_out, float focus_strength, int B, int N,
+                                  void* stream) {
+  if (B <= 0 || N <= 0) return COGAIM_EINVAL;
+  const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
+  hipLaunchKernelGGL(focal_attention_vector_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, part, nblk, center_bias,
+                     a, stats, scale_in, scale_out, focus_strength, N);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+// flags[slot] = (unbiased variance over the whole [B,N] batch < 1e-6)
+int cogaim_focal_var_flag(const double* stats, int B, int N, int* flags, int slot, void* stream) {
+  hipLaunchKernelGGL(focal_var_flag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, B, N, flags, slot);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+int cogaim_focal_reduce_u(const float* part, float* u, float* usum, int B, int N, void* stream) {
+  if (B <= 0 || N <= 0) return COGAIM_EINVAL;
+  const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
+  hipLaunchKernelGGL(focal_reduce_u_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, part, nblk, u, usum, N);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+int cogaim_weighted_tokens(const float* tok, long long tok_stride_b, const float* scale, const float* pe, const float* w,
+                           float* out, int B, int N, int D, void* stream) {
+  if (B <= 0 || N <= 0 || D <= 0) return COGAIM_EINVAL;
+  hipLaunchKernelGGL(focal_weighted_tokens_kernel, dim3((D + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, tok,
+                     tok_stride_b, scale, pe, w, out, N, D);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+int cogaim_guided_attention(const float* a, const float* mask, float* out, int B, int N, float alpha, float temperature,
+                            void* stream) {
+  if (B <= 0 || N <= 0 || temperature <= 0.f) return COGAIM_EINVAL;
+  hipLaunchKernelGGL(guided_attention_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, mask, out, N, alpha,
+                     1.0f / temperature);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -1,0 +1,281 @@
+// MFMA GEMM for gfx950:  C[M,N] = A[M,K] * W[N,K]^T  (both operands K-contiguous,
+// 16-bit bf16/fp16, fp32 accumulate) with the fused epilogues the DINOv2 blocks
+// and the focal stream need.
+//
+// Tile 128x128x64, 256 threads = 4 waves as 2(M) x 2(N), each wave 64x64 =
+// 4x4 v_mfma_f32_16x16x32 tiles.  Operand tiles are staged global -> LDS with
+// 16-byte global_load_lds (no VGPR round trip) into two buffers; the LDS image
+// is [row][8 x 16-B chunk] with the chunk index XORed by (row>>1)&7, applied on
+// the per-lane SOURCE address (the DMA destination is lane-linear) and again on
+// the ds_read_b128 fragment reads, which makes those reads bank-conflict free.
+// Rows past M / N are clamped on load and masked on store, so no padding of the
+// caller's buffers is needed.  K must be a multiple of 64.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+
+struct GemmShape {
+  const void* A; const void* W;
+  int M, N, K, lda, ldw;
+  long long strideA, strideW;   // per blockIdx.y batch, in elements
+};
+
+// ---- epilogues -------------------------------------------------------------
+// SWAP orientation: store4n(z, m, n0, v) gets C[m][n0..n0+3].
+// plain orientation: store4m(z, m0, n, v) gets C[m0..m0+3][n].
+
+template <class T> struct EpiBiasHalf {           // out16 = (acc + bias) [* scale for n < scale_cols]
+  T* out; const float* bias; int ldc; int scale_cols; float scale; int M, N;
+  __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
+    if (m >= M || n0 >= N) return;
+    float s = n0 < scale_cols ? scale : 1.0f;
+    const float4 b = *reinterpret_cast<const float4*>(bias + n0);
+    *reinterpret_cast<Half4<T>*>(out + (size_t)m * ldc + n0) =
+        to_half4<T>((v[0] + b.x) * s, (v[1] + b.y) * s, (v[2] + b.z) * s, (v[3] + b.w) * s);
+  }
+};
+
+__device__ __forceinline__ float gelu_erf(float x) {  // exact GELU (hidden_act="gelu")
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+template <class T> struct EpiBiasGeluHalf {
+  T* out; const float* bias; int ldc; int M, N;
+  __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
+    if (m >= M || n0 >= N) return;
+    const float4 b = *reinterpret_cast<const float4*>(bias + n0);
+    *reinterpret_cast<Half4<T>*>(out + (size_t)m * ldc + n0) =
+        to_half4<T>(gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y), gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w));
+  }
+};
+
+struct EpiResidualF32 {                            // x += (acc + bias) * layerscale   (in place)
+  float* x; const float* bias; const float* ls; int ldc; int M, N;
+  __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
+    if (m >= M || n0 >= N) return;
+    const float4 b = *reinterpret_cast<const float4*>(bias + n0);
+    const float4 l = *reinterpret_cast<const float4*>(ls + n0);
+    float4* p = reinterpret_cast<float4*>(x + (size_t)m * ldc + n0);
+    float4 r = *p;
+    r.x += (v[0] + b.x) * l.x; r.y += (v[1] + b.y) * l.y;
+    r.z += (v[2] + b.z) * l.z; r.w += (v[3] + b.w) * l.w;
+    *p = r;
+  }
+};
+
+struct EpiStoreF32 {                               // batched plain fp32 store (focal scores)
+  float* out; int ldc; long long strideC; int M, N;
+  __device__ __forceinline__ void store4n(int z, int m, int n0, f32x4 v) const {
+    if (m >= M || n0 >= N) return;
+    *reinterpret_cast<float4*>(out + z * strideC + (size_t)m * ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+
+struct EpiPatchEmbed {                             // token row b*T+1+p = acc + bias + pos[1+p]
+  float* x; const float* bias; const float* pos; int D; int P; int M;   // P patches per image
+  __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
+    if (m >= M || n0 >= D) return;
+    const int b = m / P, p = m - b * P;
+    const float4 bi = *reinterpret_cast<const float4*>(bias + n0);
+    const float4 po = *reinterpret_cast<const float4*>(pos + (size_t)(1 + p) * D + n0);
+    *reinterpret_cast<float4*>(x + ((size_t)b * (P + 1) + 1 + p) * D + n0) =
+        make_float4(v[0] + bi.x + po.x, v[1] + bi.y + po.y, v[2] + bi.z + po.z, v[3] + bi.w + po.w);
+  }
+};
+
+template <class T> struct EpiVT {                  // V^T[(b*H+h)*64 + d][t] (row length Tp), plain orientation
+  T* vt; const float* bias; int T_, Tp, M, N;
+  __device__ __forceinline__ void store4m(int, int m0, int n, f32x4 v) const {
+    if (m0 >= M || n >= N) return;
+    const float bi = bias[n];
+    const int b = m0 / T_, t = m0 - b * T_;
+    const int H = N >> 6;
+    T* row = vt + ((size_t)(b * H + (n >> 6)) * 64 + (n & 63)) * Tp;
+    if (t + 3 < T_ && m0 + 3 < M && ((t & 3) == 0)) {
+      *reinterpret_cast<Half4<T>*>(row + t) = to_half4<T>(v[0] + bi, v[1] + bi, v[2] + bi, v[3] + bi);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = m0 + j;
+        if (m < M) {
+          const int bb = m / T_, tt = m - bb * T_;
+          vt[((size_t)(bb * H + (n >> 6)) * 64 + (n & 63)) * Tp + tt] = (T)(v[j] + bi);
+        }
+      }
+    }
+  }
+};
+
+// ---- staging ---------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// bijective XCD-aware remap: blocks that share an XCD (bid % 8) get a contiguous tile range
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <class T, class Epi, bool SWAP>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmShape g, Epi epi) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // [stage][A|W]
+  using H = Half<T>;
+  using v8 = typename H::v8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int z = blockIdx.y;
+  const T* A = reinterpret_cast<const T*>(g.A) + z * g.strideA;
+  const T* W = reinterpret_cast<const T*>(g.W) + z * g.strideW;
+
+  // per-lane source pointers for the 4 DMA instructions per operand per stage
+  const T* srcA[4]; const T* srcW[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave * 32 + i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int ra = tm * BM + r; ra = ra < g.M ? ra : g.M - 1;
+    int rw = tn * BN + r; rw = rw < g.N ? rw : g.N - 1;
+    srcA[i] = A + (size_t)ra * g.lda + c * 8;
+    srcW[i] = W + (size_t)rw * g.ldw + c * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+    char* a = smem + buf * 2 * TILE_BYTES + wave * 32 * 128;
+    char* w = a + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(srcA[i] + k0, a + i * 8 * 128);
+      glds16(srcW[i] + k0, w + i * 8 * 128);
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rowA = wm * 64 + fr, rowW = wn * 64 + fr;       // + 16*i
+  const int swA = (rowA >> 1) & 7, swW = (rowW >> 1) & 7;   // unchanged by + 16*i
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK;
+  stage(0, 0);
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
+    const char* as = smem + (t & 1) * 2 * TILE_BYTES;
+    const char* ws = as + TILE_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      v8 af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *reinterpret_cast<const v8*>(as + (rowA + 16 * i) * 128 + (((4 * s + fq) ^ swA) << 4));
+        wf[i] = *reinterpret_cast<const v8*>(ws + (rowW + 16 * i) * 128 + (((4 * s + fq) ^ swW) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = SWAP ? H::mfma16(wf[j], af[i], acc[i][j]) : H::mfma16(af[i], wf[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  const int m_base = tm * BM + wm * 64, n_base = tn * BN + wn * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (SWAP) epi.store4n(z, m_base + 16 * i + fr, n_base + 16 * j + 4 * fq, acc[i][j]);
+      else epi.store4m(z, m_base + 16 * i + 4 * fq, n_base + 16 * j + fr, acc[i][j]);
+    }
+}
+
+template <class T, class Epi, bool SWAP>
+int launch(const GemmShape& g, const Epi& epi, int batch, hipStream_t st) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (g.N & 3) != 0 ||
+      (g.lda & 7) != 0 || (g.ldw & 7) != 0)
+    return COGAIM_EINVAL;
+  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  hipLaunchKernelGGL((gemm_kernel<T, Epi, SWAP>), dim3(tiles, batch), dim3(256), 0, st, g, epi);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F16) \
+  ((dtype) == 0 ? (CALL_BF16) : (dtype) == 1 ? (CALL_F16) : COGAIM_EINVAL)
+
+extern "C" {
+
+// out16[M,N] = (A * W^T + bias), columns [0, scale_cols) additionally multiplied by scale.
+int cogaim_gemm_bias_half(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                          int lda, int ldw, int ldc, int scale_cols, float scale, int dtype, void* stream) {
+  GemmShape g{A, W, M, N, K, lda, ldw, 0, 0};
+  if (ldc & 3) return COGAIM_EINVAL;
+  return DISPATCH_T(dtype,
+      (launch<__bf16, EpiBiasHalf<__bf16>, true>(g, {(__bf16*)out, bias, ldc, scale_cols, scale, M, N}, 1, (hipStream_t)stream)),
+      (launch<_Float16, EpiBiasHalf<_Float16>, true>(g, {(_Float16*)out, bias, ldc, scale_cols, scale, M, N}, 1, (hipStream_t)stream)));
+}
+
+// out16[M,N] = gelu_erf(A * W^T + bias)
+int cogaim_gemm_bias_gelu_half(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                               int lda, int ldw, int ldc, int dtype, void* stream) {
+  GemmShape g{A, W, M, N, K, lda, ldw, 0, 0};
+  if (ldc & 3) return COGAIM_EINVAL;
+  return DISPATCH_T(dtype,
+      (launch<__bf16, EpiBiasGeluHalf<__bf16>, true>(g, {(__bf16*)out, bias, ldc, M, N}, 1, (hipStream_t)stream)),
+      (launch<_Float16, EpiBiasGeluHalf<_Float16>, true>(g, {(_Float16*)out, bias, ldc, M, N}, 1, (hipStream_t)stream)));
+}
+
+// x[M,N] += (A * W^T + bias) * layerscale      (fp32 residual stream, in place)
+int cogaim_gemm_residual_f32(const void* A, const void* W, const float* bias, const float* layerscale, float* x,
+                             int M, int N, int K, int lda, int ldw, int ldc, int dtype, void* stream) {
+  GemmShape g{A, W, M, N, K, lda, ldw, 0, 0};
+  if (ldc & 3) return COGAIM_EINVAL;
+  EpiResidualF32 e{x, bias, layerscale, ldc, M, N};
+  return DISPATCH_T(dtype, (launch<__bf16, EpiResidualF32, true>(g, e, 1, (hipStream_t)stream)),
+                    (launch<_Float16, EpiResidualF32, true>(g, e, 1, (hipStream_t)stream)));
+}
+
+// out32[z][M,N] = A[z] * W[z]^T for z < batch (strides in elements)
+int cogaim_gemm_batched_f32(const void* A, const void* W, float* out, int M, int N, int K, int lda, int ldw, int ldc,
+                            long long strideA, long long strideW, long long strideC, int batch, int dtype,
+                            void* stream) {
+  GemmShape g{A, W, M, N, K, lda, ldw, strideA, strideW};
+  if ((ldc & 3) || (strideC & 3) || (strideA & 7) || (strideW & 7) || batch <= 0) return COGAIM_EINVAL;
+  EpiStoreF32 e{out, ldc, strideC, M, N};
+  return DISPATCH_T(dtype, (launch<__bf16, EpiStoreF32, true>(g, e, batch, (hipStream_t)stream)),
+                    (launch<_Float16, EpiStoreF32, true>(g, e, batch, (hipStream_t)stream)));
+}
+
+// Patch-embedding GEMM: rows are im2col'ed patches (B*P rows, K padded to a multiple of 64);
+// writes token rows 1..P of x[B, P+1, D] = acc + bias + pos[1+p].
+int cogaim_gemm_patch_embed(const void* cols, const void* W, const float* bias, const float* pos, float* x,
+                            int B, int P, int D, int K, int dtype, void* stream) {
+  GemmShape g{cols, W, B * P, D, K, K, K, 0, 0};
+  EpiPatchEmbed e{x, bias, pos, D, P, B * P};
+  return DISPATCH_T(dtype, (launch<__bf16, EpiPatchEmbed, true>(g, e, 1, (hipStream_t)stream)),
+                    (launch<_Float16, EpiPatchEmbed, true>(g, e, 1, (hipStream_t)stream)));
+}
+
+// V projection written transposed per head: vt[(b*H+h)*64+d][t] = A[b*T+t] . W[h*64+d] + bias, row length Tp.
+int cogaim_gemm_vt(const void* A, const void* W, const float* bias, void* vt, int B, int T, int D, int K, int lda,
+                   int ldw, int Tp, int dtype, void* stream) {
+  if ((D & 63) || Tp < T || (Tp & 3)) return COGAIM_EINVAL;
+  GemmShape g{A, W, B * T, D, K, lda, ldw, 0, 0};
+  return DISPATCH_T(dtype,
+      (launch<__bf16, EpiVT<__bf16>, false>(g, {(__bf16*)vt, bias, T, Tp, B * T, D}, 1, (hipStream_t)stream)),
+      (launch<_Float16, EpiVT<_Float16>, false>(g, {(_Float16*)vt, bias, T, Tp, B * T, D}, 1, (hipStream_t)stream)));
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+// Row-wise HBM-bound kernels of the DINOv2 path: LayerNorm (fp32 residual
+// stream -> 16-bit GEMM operand, or -> fp32 for the final norm), the im2col
+// gather that feeds the patch-embedding GEMM, and the CLS-token row.
+// One 64-lane wave per row, 16-byte loads, wave-shuffle reductions.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAX_VEC = 8;   // float4 per lane -> D <= 2048
+
+template <class OutT, bool F32OUT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, void* __restrict__ out,
+                                                        int M, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+  const int nv = D >> 2;
+  float4 v[LN_MAX_VEC];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      v[i] = xr[c];
+      sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      sq += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+      const float4 b = reinterpret_cast<const float4*>(beta)[c];
+      const float y0 = (v[i].x - mean) * rstd * g.x + b.x, y1 = (v[i].y - mean) * rstd * g.y + b.y;
+      const float y2 = (v[i].z - mean) * rstd * g.z + b.z, y3 = (v[i].w - mean) * rstd * g.w + b.w;
+      if constexpr (F32OUT)
+        reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * D)[c] = make_float4(y0, y1, y2, y3);
+      else
+        reinterpret_cast<Half4<OutT>*>(reinterpret_cast<OutT*>(out) + (size_t)row * D)[c] =
+            to_half4<OutT>(y0, y1, y2, y3);
+    }
+  }
+}
+
+// images [B,3,H,W] fp32 -> cols [B*gh*gw, Kp] 16-bit, column c*p*p + ky*p + kx, zero padded to Kp.
+template <class T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, T* __restrict__ cols, int B,
+                                                     int Himg, int Wimg, int gh, int gw, int p, int Kp) {
+  const int chunks = Kp >> 3;
+  const long long total = (long long)B * gh * gw * chunks;
+  const int K = 3 * p * p;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ch = (int)(i % chunks);
+    const long long row = i / chunks;
+    const int px = (int)(row % gw);
+    const int py = (int)((row / gw) % gh);
+    const int b = (int)(row / ((long long)gw * gh));
+    alignas(16) T o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = ch * 8 + j;
+      float val = 0.f;
+      if (k < K) {
+        const int c = k / (p * p), rem = k - c * p * p, ky = rem / p, kx = rem - ky * p;
+        val = img[(((size_t)b * 3 + c) * Himg + (py * p + ky)) * Wimg + px * p + kx];
+      }
+      o[j] = (T)val;
+    }
+    *reinterpret_cast<uint4*>(cols + row * Kp + ch * 8) = *reinterpret_cast<const uint4*>(o);
+  }
+}
+
+__global__ void cls_row_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ x,
+                               int B, int T, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, d = i - b * D;
+  x[(size_t)b * T * D + d] = cls[d] + pos[d];
+}
+
+}  // namespace
+
+extern "C" {
+
+// out[M,D] = LayerNorm(x[M,D]) * gamma + beta.  out_dtype: 0 bf16, 1 fp16, 2 fp32.
+int cogaim_layernorm(const float* x, const float* gamma, const float* beta, void* out, int M, int D, float eps,
+                     int out_dtype, void* stream) {
+  if (M <= 0 || (D & 3) || D > 256 * LN_MAX_VEC) return COGAIM_EINVAL;
+  dim3 grid((M + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == 0) hipLaunchKernelGGL((layernorm_kernel<__bf16, false>), grid, block, 0, st, x, gamma, beta, out, M, D, eps);
+  else if (out_dtype == 1) hipLaunchKernelGGL((layernorm_kernel<_Float16, false>), grid, block, 0, st, x, gamma, beta, out, M, D, eps);
+  else if (out_dtype == 2) hipLaunchKernelGGL((layernorm_kernel<float, true>), grid, block, 0, st, x, gamma, beta, out, M, D, eps);
+  else return COGAIM_EINVAL;
+  return COGAIM_LAUNCH_CHECK();
+}
+
+int cogaim_im2col(const float* images, void* cols, int B, int H, int W, int patch, int Kp, int dtype, void* stream) {
+  const int gh = H / patch, gw = W / patch;
+  if (B <= 0 || gh <= 0 || gw <= 0 || (Kp & 7) || Kp < 3 * patch * patch) return COGAIM_EINVAL;
+  const long long total = (long long)B * gh * gw * (Kp >> 3);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL(im2col_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, images, (__bf16*)cols, B, H, W, gh, gw, patch, Kp);
+  else if (dtype == 1) hipLaunchKernelGGL(im2col_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, images, (_Float16*)cols, B, H, W, gh, gw, patch, Kp);
+  else return COGAIM_EINVAL;
+  return COGAIM_LAUNCH_CHECK();
+}
+
+// x[b, 0, :] = cls + pos[0]   (x is [B, T, D] fp32)
+int cogaim_cls_row(const float* cls, const float* pos, float* x, int B, int T, int D, void* stream) {
+  if (B <= 0 || T <= 0 || D <= 0) return COGAIM_EINVAL;
+  hipLaunchKernelGGL(cls_row_kernel, dim3((B * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, cls, pos, x, B, T, D);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+}  // extern "C"

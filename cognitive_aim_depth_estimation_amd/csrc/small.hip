@@ -1,0 +1,106 @@
+// Small fp32 kernels for the per-image MLPs and heads (reference
+// src/model.py:32-53 ambient, :311 focal projection, :342-346 focal fusion,
+// :482-519 EXIF prior, :908-941 fusion / decision / confidence heads).
+// Batch-many-rows x few-hundred-columns: GEMV class, one wave per output.
+#include "common.h"
+
+namespace {
+
+// out[b*ldo + o] = act(x[b*ldx + :K] . W[o*K + :K] + bias[o] * (bias_scale ? bias_scale[b] : 1))
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ x, int ldx,
+                                                         const float* __restrict__ W, const float* __restrict__ bias,
+                                                         const float* __restrict__ bias_scale, float* __restrict__ out,
+                                                         int ldo, int B, int O, int K, int act) {
+  const int lane = threadIdx.x & 63;
+  const long long wid = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (wid >= (long long)B * O) return;
+  const int b = (int)(wid / O), o = (int)(wid - (long long)b * O);
+  const float* xr = x + (size_t)b * ldx;
+  const float* wr = W + (size_t)o * K;
+  float acc = 0.f;
+  if (((K | ldx) & 3) == 0) {
+    for (int k = lane * 4; k < K; k += 256) {
+      const float4 a = *reinterpret_cast<const float4*>(xr + k);
+      const float4 w = *reinterpret_cast<const float4*>(wr + k);
+      acc += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);
+    }
+  } else {
+    for (int k = lane; k < K; k += 64) acc += xr[k] * wr[k];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    float bv = bias ? bias[o] : 0.f;
+    if (bias_scale) bv *= bias_scale[b];
+    float y = acc + bv;
+    if (act == 1) y = fmaxf(y, 0.f);
+    out[(size_t)b * ldo + o] = y;
+  }
+}
+
+// feat[b][0:E] = emb[idx[b]][0:E];  cont[b] = {focal_length, aperture, log(iso + 1)}
+__global__ void exif_prep_kernel(const long long* __restrict__ idx, const float* __restrict__ fl,
+                                 const float* __restrict__ ap, const float* __restrict__ iso,
+                                 const float* __restrict__ emb, int E, float* __restrict__ feat, int ldf,
+                                 float* __restrict__ cont, int B) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (b >= B) return;
+  for (int e = t; e < E; e += blockDim.x) feat[(size_t)b * ldf + e] = emb[(size_t)idx[b] * E + e];
+  if (t == 0) { cont[b * 3] = fl[b]; cont[b * 3 + 1] = ap[b]; cont[b * 3 + 2] = logf(iso[b] + 1.0f); }
+}
+
+// depth = softplus(f . wd + bd) (beta 1, threshold 20); conf = sigmoid(w2 * relu(f . wc + bc) + b2)
+__global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ fused, int K, const float* __restrict__ wd,
+                                                    const float* __restrict__ bd, const float* __restrict__ wc,
+                                                    const float* __restrict__ bc, const float* __restrict__ w2,
+                                                    const float* __restrict__ b2, float* __restrict__ depth,
+                                                    float* __restrict__ conf, int B) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float ad = 0.f, ac = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float f = fused[(size_t)b * K + k];
+    ad += f * wd[k]; ac += f * wc[k];
+  }
+  ad = wave_sum(ad); ac = wave_sum(ac);
+  if (lane == 0) {
+    const float zd = ad + bd[0];
+    depth[b] = zd > 20.f ? zd : log1pf(expf(zd));
+    const float zc = fmaxf(ac + bc[0], 0.f) * w2[0] + b2[0];
+    conf[b] = 1.0f / (1.0f + expf(-zc));
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// act: 0 identity, 1 ReLU.  bias / bias_scale may be NULL.
+int cogaim_linear_f32(const float* x, int ldx, const float* W, const float* bias, const float* bias_scale, float* out,
+                      int ldo, int B, int O, int K, int act, void* stream) {
+  if (B <= 0 || O <= 0 || K <= 0 || ldx < K || (act != 0 && act != 1)) return COGAIM_EINVAL;
+  const long long waves = (long long)B * O;
+  hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, W,
+                     bias, bias_scale, out, ldo, B, O, K, act);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+int cogaim_exif_prep(const long long* camera_idx, const float* focal_length, const float* aperture, const float* iso,
+                     const float* embedding, int emb_dim, float* feat, int ldf, float* cont, int B, void* stream) {
+  if (B <= 0 || emb_dim <= 0 || ldf < emb_dim) return COGAIM_EINVAL;
+  hipLaunchKernelGGL(exif_prep_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, camera_idx, focal_length, aperture,
+                     iso, embedding, emb_dim, feat, ldf, cont, B);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+int cogaim_heads(const float* fused, int K, const float* wd, const float* bd, const float* wc, const float* bc,
+                 const float* w2, const float* b2, float* depth, float* conf, int B, void* stream) {
+  if (B <= 0 || K <= 0) return COGAIM_EINVAL;
+  hipLaunchKernelGGL(heads_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, fused, K, wd, bd, wc, bc, w2,
+                     b2, depth, conf, B);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+int cogaim_version() { return 1; }
+
+}  // extern "C"

@@ -1,0 +1,651 @@
+"""MI355X-native Cognitive-Aim model behind the reference's nn.Module API.
+
+Drop-in for reference ``src/model.py``: ``create_model(config, camera_info,
+device)`` (:1534), ``CognitiveAimModel.forward(images, exif_data,
+return_attention)`` (:1064), ``forward_with_guidance`` (:1157),
+``get_attention_weights`` (:1058), ``get_features`` (:1428), the
+``use_ambient / use_focal / use_exif`` attributes and a ``state_dict`` with the
+reference's exact keys and shapes, so ``demo.py``-style checkpoint loading
+works unchanged.
+
+All arithmetic runs in hand-written gfx950 kernels (libcogaim.so, bound in
+``_lib.py``); torch only owns device memory and streams.  There is no CPU or
+eager fallback: tensors must live on a ROCm device.
+
+Differences from the reference that are deliberate:
+  * each call runs the backbone and the iterative focal stream once; the
+    reference repeats them 2-4x per call with bit-identical results
+    (:1008/:1021/:1095/:1129);
+  * the curiosity module (:521-793) is not evaluated: its score never reaches
+    the outputs when ``curiosity_guided`` is off (the only setting the shipped
+    configs produce) and cancels in the renormalisation of :282 otherwise; its
+    parameters and buffers are kept for ``state_dict`` compatibility;
+  * kernel launch errors raise instead of being turned into all-zero features
+    (:1050-1056).
+"""
+from __future__ import annotations
+
+import math
+import os
+from collections import OrderedDict
+from typing import Dict, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import tables
+from ._lib import call, ptr, stream_ptr
+
+LOG2E = 1.4426950408889634
+_DTYPES = {"bf16": (0, torch.bfloat16), "fp16": (1, torch.float16)}
+
+
+# --------------------------------------------------------------------------
+# parameter layout
+# --------------------------------------------------------------------------
+def state_spec(hidden: int, layers: int, patch: int, native_grid: int, num_iterations: int,
+               num_cameras: int, use_ambient: bool, use_focal: bool, use_exif: bool,
+               curiosity_guided: bool) -> "OrderedDict[str, Tuple[tuple, torch.dtype]]":
+    """Key -> (shape, dtype) in the reference's registration order."""
+    D, f32 = hidden, torch.float32
+    s: "OrderedDict[str, Tuple[tuple, torch.dtype]]" = OrderedDict()
+
+    def lin(name, o, i):
+        s[name + ".weight"] = ((o, i), f32)
+        s[name + ".bias"] = ((o,), f32)
+
+    e = "backbone.embeddings."
+    s[e + "cls_token"] = ((1, 1, D), f32)
+    s[e + "mask_token"] = ((1, D), f32)
+    s[e + "position_embeddings"] = ((1, native_grid ** 2 + 1, D), f32)
+    s[e + "patch_embeddings.projection.weight"] = ((D, 3, patch, patch), f32)
+    s[e + "patch_embeddings.projection.bias"] = ((D,), f32)
+    for i in range(layers):
+        p = f"backbone.encoder.layer.{i}."
+        for n in ("norm1.weight", "norm1.bias"):
+            s[p + n] = ((D,), f32)
+        for n in ("query", "key", "value"):
+            lin(p + "attention.attention." + n, D, D)
+        lin(p + "attention.output.dense", D, D)
+        s[p + "layer_scale1.lambda1"] = ((D,), f32)
+        for n in ("norm2.weight", "norm2.bias"):
+            s[p + n] = ((D,), f32)
+        lin(p + "mlp.fc1", 4 * D, D)
+        lin(p + "mlp.fc2", D, 4 * D)
+        s[p + "layer_scale2.lambda1"] = ((D,), f32)
+    s["backbone.layernorm.weight"] = ((D,), f32)
+    s["backbone.layernorm.bias"] = ((D,), f32)
+    if use_ambient:
+        lin("ambient_stream.mlp.0", 256, D)
+        lin("ambient_stream.mlp.3", 128, 256)
+        lin("ambient_stream.mlp.5", 64, 128)
+    if use_focal:
+        s["focal_stream.initial_focus"] = ((1, D), f32)
+        for i in range(num_iterations):
+            p = f"focal_stream.focal_streams.{i}."
+            s[p + "adaptive_weight"] = ((), f32)
+            for n in ("query_proj", "key_proj", "value_proj"):
+                lin(p + n, D, D)
+            if curiosity_guided:
+                lin(p + "curiosity_modulator.0", 32, 1)
+                lin(p + "curiosity_modulator.2", 8, 32)
+            lin(p + "projection.0", 256, D)
+            lin(p + "projection.3", 64, 256)
+        if curiosity_guided:
+            lin("focal_stream.curiosity_amplifier.0", 32, 1)
+            lin("focal_stream.curiosity_amplifier.2", num_iterations, 32)
+        lin("focal_stream.fusion.0", 128, 64 * num_iterations)
+        lin("focal_stream.fusion.2", 64, 128)
+    if use_exif:
+        s["exif_prior.camera_embedding.weight"] = ((num_cameras, 64), f32)
+        lin("exif_prior.exif_encoder.0", 64, 3)
+        lin("exif_prior.exif_encoder.2", 64, 64)
+        lin("exif_prior.fusion.0", 256, 128)
+        lin("exif_prior.fusion.3", 64, 256)
+    lin("fusion.0", 192, 192)
+    for n in ("ambient", "focal", "exif"):
+        lin(n + "_dim_aligner.projection", 768, 64)
+    lin("decision_head.0", 1, 192)
+    lin("confidence_head.0", 1, 192)
+    lin("confidence_head.2", 1, 1)
+    c = "curiosity_module."
+    s[c + "curiosity_weights"] = ((3,), f32)
+    s[c + "exploration_history"] = ((1000,), f32)
+    s[c + "history_pointer"] = ((), torch.int64)
+    for n, o, i in (("encoder_mean.0", 384, 768), ("encoder_mean.3", 192, 384),
+                    ("encoder_logvar.0", 384, 768), ("encoder_logvar.3", 192, 384),
+                    ("decoder.0", 384, 192), ("decoder.3", 192, 384),
+                    ("uncertainty_head.0", 192, 768), ("uncertainty_head.2", 1, 192),
+                    ("geometric_curiosity.0", 256, 772), ("geometric_curiosity.2", 1, 256),
+                    ("local_curiosity.0", 128, 768), ("local_curiosity.2", 1, 128)):
+        lin(c + n, o, i)
+    lin("global_aligner.projection", 768, 2304)
+    return s
+
+
+_BUFFERS = ("curiosity_module.exploration_history", "curiosity_module.history_pointer")
+
+
+def _init_tensor(key: str, shape, dtype, gen: torch.Generator) -> torch.Tensor:
+    """Random init following the reference's distributions (src/model.py:95-126,
+    351-389, 931-945; DINOv2 trunc-normal(0.02) / LayerScale 1.0, hf:401-414).
+    Pretrained weights cannot be fetched offline; real use loads a checkpoint."""
+    leaf = key.rsplit(".", 1)[-1]
+    if dtype == torch.int64:
+        return torch.zeros(shape, dtype=dtype)
+    if key.endswith("exploration_history"):
+        return torch.zeros(shape)
+    if key.endswith("adaptive_weight"):
+        return torch.tensor(0.5)
+    if key.endswith("curiosity_weights"):
+        return torch.tensor([0.4, 0.3, 0.3])
+    if key.startswith("backbone."):
+        if "norm" in key:
+            return torch.ones(shape) if leaf == "weight" else torch.zeros(shape)
+        if leaf == "lambda1":
+            return torch.ones(shape)
+        if leaf == "bias" or leaf == "mask_token":
+            return torch.zeros(shape)
+        return torch.nn.init.trunc_normal_(torch.empty(shape), std=0.02, generator=gen)
+    if key == "focal_stream.initial_focus":
+        return torch.randn(shape, generator=gen) * 0.02
+    if key == "decision_head.0.bias":
+        return torch.ones(shape)
+    if key == "confidence_head.2.bias":
+        return torch.full(shape, 2.0)
+    if leaf == "weight" and len(shape) == 2:
+        o, i = shape
+        if key.endswith("camera_embedding.weight"):
+            return torch.randn(shape, generator=gen)
+        if ".focal_streams." in key and ("query_proj" in key or "key_proj" in key or "value_proj" in key):
+            it = int(key.split(".focal_streams.")[1].split(".")[0])
+            gain = (1.0 if "value_proj" in key else 1.2) * (1.0 + 0.1 * it)
+            return torch.randn(shape, generator=gen) * (gain * math.sqrt(2.0 / (i + o)))
+        if key.startswith("focal_stream.") or key == "decision_head.0.weight":
+            gain = 1.0 if key == "decision_head.0.weight" else 0.8
+            bound = gain * math.sqrt(6.0 / (i + o))
+            return (torch.rand(shape, generator=gen) * 2 - 1) * bound
+        bound = 1.0 / math.sqrt(i)       # nn.Linear default (kaiming_uniform a=sqrt(5))
+        return (torch.rand(shape, generator=gen) * 2 - 1) * bound
+    if leaf == "bias":
+        if ".focal_streams." in key and ("query_proj" in key or "key_proj" in key):
+            it = int(key.split(".focal_streams.")[1].split(".")[0])
+            return (torch.rand(shape, generator=gen) * 2 - 1) * 0.01 * (1.0 + 0.1 * it)
+        if key.startswith("focal_stream."):
+            return torch.zeros(shape)
+        return torch.zeros(shape)
+    return torch.randn(shape, generator=gen) * 0.02
+
+
+class _Node(nn.Module):
+    """Bare container: exists only to give parameters the reference's dotted names."""
+
+
+# --------------------------------------------------------------------------
+# model
+# --------------------------------------------------------------------------
+class CognitiveAimModel(nn.Module):
+    def __init__(self, config: dict, camera_info: Optional[dict] = None):
+        super().__init__()
+        self.config = config
+        # -- config resolution, same keys and defaults as reference src/model.py:803-951 --
+        self.backbone_size = config.get("backbone_size", "base")
+        self.feature_dim = 1024 if self.backbone_size == "large" else 768
+        if self.feature_dim != 768:
+            raise NotImplementedError("only the dinov2-base geometry (768 wide) is built; the reference's "
+                                      "own heads are hard-wired to 768 as well (src/model.py:918,949)")
+        self.use_lora = config.get("use_lora", False)
+        if self.use_lora:
+            raise NotImplementedError("LoRA is unused and broken in the reference (src/model.py:30)")
+        model_cfg = config.get("model", {}) or {}
+        modules = model_cfg.get("cognitive_modules", config.get("cognitive_modules", []))
+        self.use_ambient = "ambient_stream" in modules
+        cg = config.get("curiosity_guided_attention", {}) or {}
+        self.curiosity_guided = bool(cg.get("enabled", False))
+        focal_cfg = config.get("focal_config", {}) or {}
+        if "iterative_focal_stream" in modules:
+            self.use_focal, self.use_iterative = True, True
+            self.num_iterations = int(focal_cfg.get("num_iterations", 3))
+            self.focus_strength = float(focal_cfg.get("focus_strength", 1.5))
+            if config.get("focal_hidden_dim", 256) != 256:
+                raise NotImplementedError("focal_hidden_dim != 256")
+        elif "focal_stream" in modules:
+            raise NotImplementedError("the non-iterative 'focal_stream' module is not built; every shipped "
+                                      "config selects 'iterative_focal_stream'")
+        else:
+            self.use_focal, self.use_iterative = False, False
+            self.num_iterations, self.focus_strength = 0, 0.0
+        self.use_exif = bool("exif_prior_database" in modules and camera_info)
+        num_cameras = int(camera_info["num_cameras"]) if self.use_exif else 0
+        self.fusion_dim = 192
+        self.target_fusion_dim = 768
+        # -- backbone geometry: dinov2-base unless overridden (tests use shallow stacks) --
+        bb = config.get("backbone_config", {}) or {}
+        self.num_layers = int(bb.get("num_hidden_layers", 12))
+        self.num_heads = int(bb.get("num_attention_heads", 12))
+        self.patch_size = int(bb.get("patch_size", 14))
+        self.native_grid = int(bb.get("image_size", 518)) // self.patch_size
+        self.layer_norm_eps = float(bb.get("layer_norm_eps", 1e-6))
+        if self.feature_dim != 64 * self.num_heads:
+            raise NotImplementedError("attention kernel is built for head_dim 64")
+        self.compute_dtype = str(config.get("compute_dtype", os.environ.get("COGAIM_DTYPE", "bf16")))
+        if self.compute_dtype not in _DTYPES:
+            raise ValueError(f"compute_dtype must be one of {sorted(_DTYPES)}")
+
+        spec = state_spec(self.feature_dim, self.num_layers, self.patch_size, self.native_grid,
+                          self.num_iterations, num_cameras, self.use_ambient, self.use_focal,
+                          self.use_exif, self.curiosity_guided)
+        gen = torch.Generator().manual_seed(int(config.get("init_seed", 0)))
+        for key, (shape, dtype) in spec.items():
+            node = self
+            parts = key.split(".")
+            for p in parts[:-1]:
+                if not hasattr(node, p):
+                    node.add_module(p, _Node())
+                node = getattr(node, p)
+            t = _init_tensor(key, tuple(shape), dtype, gen)
+            if key in _BUFFERS:
+                node.register_buffer(parts[-1], t)
+            else:
+                node.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
+        self._packed = None
+        self._packed_sig = None
+        self._ws: Dict[tuple, dict] = {}
+        self._tab: Dict[tuple, torch.Tensor] = {}
+        self.fusion_features = None
+
+    # ------------------------------------------------------------------ packing
+    def _signature(self):
+        sig = [self.compute_dtype]
+        for p in self.parameters():
+            sig.append((p.data_ptr(), p._version))
+        return tuple(sig)
+
+    def _pack(self):
+        """16-bit copies of the GEMM weights, fused QK matrices; refreshed whenever a
+        parameter was replaced or modified in place (load_state_dict, .to())."""
+        sig = self._signature()
+        if self._packed is not None and sig == self._packed_sig:
+            return self._packed
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        dev = sd["backbone.layernorm.weight"].device
+        if dev.type != "cuda":
+            raise RuntimeError("CognitiveAimModel runs only on a ROCm device (no CPU path): call "
+                               ".to('cuda') / create_model(..., device='cuda')")
+        _, tdt = _DTYPES[self.compute_dtype]
+        D = self.feature_dim
+        pk: Dict[str, object] = {"device": dev}
+        w = sd["backbone.embeddings.patch_embeddings.projection.weight"].reshape(D, -1)
+        kp = (w.shape[1] + 63) // 64 * 64
+        wp = torch.zeros(D, kp, device=dev, dtype=tdt)
+        wp[:, :w.shape[1]] = w.to(tdt)
+        pk["pe_w"], pk["pe_kp"] = wp, kp
+        pk["pe_b"] = sd["backbone.embeddings.patch_embeddings.projection.bias"].float().contiguous()
+        pk["cls"] = sd["backbone.embeddings.cls_token"].float().reshape(D).contiguous()
+        layers = []
+        for i in range(self.num_layers):
+            p = f"backbone.encoder.layer.{i}."
+            a = p + "attention.attention."
+            layers.append({
+                "g1": sd[p + "norm1.weight"].float().contiguous(), "b1": sd[p + "norm1.bias"].float().contiguous(),
+                "wqk": torch.cat([sd[a + "query.weight"], sd[a + "key.weight"]], 0).to(tdt).contiguous(),
+                "bqk": torch.cat([sd[a + "query.bias"], sd[a + "key.bias"]], 0).float().contiguous(),
+                "wv": sd[a + "value.weight"].to(tdt).contiguous(), "bv": sd[a + "value.bias"].float().contiguous(),
+                "wo": sd[p + "attention.output.dense.weight"].to(tdt).contiguous(),
+                "bo": sd[p + "attention.output.dense.bias"].float().contiguous(),
+                "ls1": sd[p + "layer_scale1.lambda1"].float().contiguous(),
+                "g2": sd[p + "norm2.weight"].float().contiguous(), "b2": sd[p + "norm2.bias"].float().contiguous(),
+                "w1": sd[p + "mlp.fc1.weight"].to(tdt).contiguous(), "bf1": sd[p + "mlp.fc1.bias"].float().contiguous(),
+                "w2": sd[p + "mlp.fc2.weight"].to(tdt).contiguous(), "bf2": sd[p + "mlp.fc2.bias"].float().contiguous(),
+                "ls2": sd[p + "layer_scale2.lambda1"].float().contiguous(),
+            })
+        pk["layers"] = layers
+        pk["gf"] = sd["backbone.layernorm.weight"].float().contiguous()
+        pk["bf"] = sd["backbone.layernorm.bias"].float().contiguous()
+        focal = []
+        for i in range(self.num_iterations):
+            p = f"focal_stream.focal_streams.{i}."
+            focal.append({
+                "wqk": torch.cat([sd[p + "query_proj.weight"], sd[p + "key_proj.weight"]], 0).to(tdt).contiguous(),
+                "bqk": torch.cat([sd[p + "query_proj.bias"], sd[p + "key_proj.bias"]], 0).float().contiguous(),
+            })
+        pk["focal"] = focal
+        pk["f32"] = {k: v.float().contiguous() for k, v in sd.items()
+                     if v.dtype.is_floating_point and not k.startswith("backbone.encoder")}
+        self._packed, self._packed_sig = pk, sig
+        self._tab.clear()
+        return pk
+
+    def _table(self, kind: str, *key) -> torch.Tensor:
+        k = (kind,) + key
+        t = self._tab.get(k)
+        if t is None:
+            dev = self._packed["device"]
+            if kind == "pos":
+                t = tables.interpolate_position_embeddings(
+                    self.state_dict()["backbone.embeddings.position_embeddings"].detach().cpu(), *key)
+            elif kind == "pe":
+                t = tables.position_table(*key)
+            elif kind == "cbias":
+                t = tables.center_bias_table(*key)
+            elif kind == "mask":
+                t = tables.instruction_mask(*key)
+            t = t.to(dev).contiguous()
+            self._tab[k] = t
+        return t
+
+    def _workspace(self, B: int, gh: int, gw: int) -> dict:
+        key = (B, gh, gw, self.compute_dtype)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        if len(self._ws) > 4:
+            self._ws.clear()
+        dev = self._packed["device"]
+        _, tdt = _DTYPES[self.compute_dtype]
+        D, H = self.feature_dim, self.num_heads
+        N = gh * gw
+        T = N + 1
+        M = B * T
+        Tp = (T + 63) // 64 * 64
+        ldS = (N + 127) // 128 * 128
+        nblk = (N + call("cogaim_focal_colsum_rows") - 1) // call("cogaim_focal_colsum_rows")
+        f32 = dict(device=dev, dtype=torch.float32)
+        h16 = dict(device=dev, dtype=tdt)
+        big_bytes = max(M * 4 * D * 2, B * N * self._packed["pe_kp"] * 2, B * N * ldS * 4 if self.use_focal else 0)
+        ws = {
+            "N": N, "T": T, "M": M, "Tp": Tp, "ldS": ldS, "nblk": nblk,
+            "x": torch.empty(M, D, **f32), "tokens": torch.empty(M, D, **f32),
+            "h": torch.empty(M, D, **h16), "qk": torch.empty(M, 2 * D, **h16),
+            "vt": torch.zeros(B * H * 64 * Tp, **h16), "ctx": torch.empty(M, D, **h16),
+            "big": torch.empty(big_bytes, device=dev, dtype=torch.uint8),
+            "rmax": torch.empty(B, N, **f32), "rinv": torch.empty(B, N, **f32),
+            "part": torch.empty(B * nblk * N, **f32), "attn": torch.empty(B, N, **f32),
+            "scale": torch.empty(2, B, N, **f32), "stats": torch.empty(B, 2, device=dev, dtype=torch.float64),
+            "flags": torch.zeros(16, device=dev, dtype=torch.int32),
+            "u": torch.empty(B, N, **f32), "usum": torch.empty(B, **f32),
+            "wt": torch.empty(B, D, **f32), "w": torch.empty(B, D, **f32),
+            "t256": torch.empty(B, 256, **f32), "t128": torch.empty(B, 128, **f32), "t64": torch.empty(B, 64, **f32),
+            "feats": torch.empty(B, 64 * max(1, self.num_iterations), **f32),
+            "exf": torch.empty(B, 128, **f32), "cont": torch.empty(B, 3, **f32),
+            "cat": torch.zeros(B, 192, **f32), "fused": torch.empty(B, 192, **f32),
+            "guided": torch.empty(B, N, **f32),
+        }
+        self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ kernels
+    def _linear(self, x, ldx, wkey, out, ldo, B, act=0, bias_scale=None, W=None, bias=None):
+        f = self._packed["f32"]
+        W = f[wkey + ".weight"] if W is None else W
+        bias = f[wkey + ".bias"] if bias is None else bias
+        O, K = W.shape
+        call("cogaim_linear_f32", x, ldx, ptr(W), ptr(bias), ptr(bias_scale), out, ldo, B, O, K, act, stream_ptr())
+
+    def _backbone(self, images: torch.Tensor, ws: dict):
+        """DINOv2 forward (hf:451-477) -> ws['tokens'] fp32 [B*T, D] (final LayerNorm applied)."""
+        pk, st = self._packed, stream_ptr()
+        dt, _ = _DTYPES[self.compute_dtype]
+        B, _, Hi, Wi = images.shape
+        p, D, H = self.patch_size, self.feature_dim, self.num_heads
+        gh, gw = Hi // p, Wi // p
+        N, T, M, Tp = ws["N"], ws["T"], ws["M"], ws["Tp"]
+        pos = self._table("pos", gh, gw)
+        x, h, qk, vt, ctx, big = (ws[k].data_ptr() for k in ("x", "h", "qk", "vt", "ctx", "big"))
+        call("cogaim_im2col", images.data_ptr(), big, B, Hi, Wi, p, pk["pe_kp"], dt, st)
+        call("cogaim_cls_row", ptr(pk["cls"]), ptr(pos), x, B, T, D, st)
+        call("cogaim_gemm_patch_embed", big, ptr(pk["pe_w"]), ptr(pk["pe_b"]), ptr(pos), x, B, N, D, pk["pe_kp"], dt, st)
+        qscale = 64 ** -0.5 * LOG2E
+        eps = self.layer_norm_eps
+        for L in pk["layers"]:
+            call("cogaim_layernorm", x, ptr(L["g1"]), ptr(L["b1"]), h, M, D, eps, dt, st)
+            call("cogaim_gemm_bias_half", h, ptr(L["wqk"]), ptr(L["bqk"]), qk, M, 2 * D, D, D, D, 2 * D, D, qscale, dt, st)
+            call("cogaim_gemm_vt", h, ptr(L["wv"]), ptr(L["bv"]), vt, B, T, D, D, D, D, Tp, dt, st)
+            call("cogaim_mhsa_fwd", qk, vt, ctx, B, T, H, Tp, 2 * D, dt, st)
+            call("cogaim_gemm_residual_f32", ctx, ptr(L["wo"]), ptr(L["bo"]), ptr(L["ls1"]), x, M, D, D, D, D, D, dt, st)
+            call("cogaim_layernorm", x, ptr(L["g2"]), ptr(L["b2"]), h, M, D, eps, dt, st)
+            call("cogaim_gemm_bias_gelu_half", h, ptr(L["w1"]), ptr(L["bf1"]), big, M, 4 * D, D, D, D, 4 * D, dt, st)
+            call("cogaim_gemm_residual_f32", big, ptr(L["w2"]), ptr(L["bf2"]), ptr(L["ls2"]), x, M, D, 4 * D, 4 * D, 4 * D, D, dt, st)
+        call("cogaim_layernorm", x, ptr(pk["gf"]), ptr(pk["bf"]), ws["tokens"].data_ptr(), M, D, eps, 2, st)
+
+    def _focal(self, B: int, ws: dict):
+        """IterativeFocalStream (src/model.py:391-455) on ws['tokens'] -> ws['cat'][:, 64:128], ws['attn']."""
+        pk, st = self._packed, stream_ptr()
+        dt, _ = _DTYPES[self.compute_dtype]
+        D, N, T, ldS = self.feature_dim, ws["N"], ws["T"], ws["ldS"]
+        tok = ws["tokens"].data_ptr() + D * 4          # skip the CLS row of every image
+        tstride = T * D
+        pe, cb = self._table("pe", N, D), self._table("cbias", N)
+        h, qk, S = ws["h"].data_ptr(), ws["qk"].data_ptr(), ws["big"].data_ptr()
+        esz = 2
+        sscale = LOG2E / math.sqrt(D // 8)             # FocalStream.scale = sqrt(patch_dim // num_heads), heads = 8
+        I = self.num_iterations
+        for i in range(I):
+            f = pk["focal"][i]
+            pfx = f"focal_stream.focal_streams.{i}."
+            s_in = None if i == 0 else ws["scale"][i % 2].data_ptr()
+            s_out = None if i == I - 1 else ws["scale"][(i + 1) % 2].data_ptr()
+            call("cogaim_focal_prep", tok, tstride, s_in, ptr(pe), h, B, N, D, dt, st)
+            call("cogaim_gemm_bias_half", h, ptr(f["wqk"]), ptr(f["bqk"]), qk, B * N, 2 * D, D, D, D, 2 * D, D, sscale, dt, st)
+            call("cogaim_gemm_batched_f32", qk, qk + D * esz, S, N, N, D, 2 * D, 2 * D, ldS,
+                 N * 2 * D, N * 2 * D, N * ldS, B, dt, st)
+            call("cogaim_focal_softmax_stats_colsum", S, ldS, N * ldS, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["part"]), B, N, st)
+            call("cogaim_focal_attention_vector", ptr(ws["part"]), ptr(cb), ptr(ws["attn"]), ptr(ws["stats"]),
+                 s_in, s_out, self.focus_strength, B, N, st)
+            call("cogaim_focal_var_flag", ptr(ws["stats"]), B, N, ptr(ws["flags"]), i % 16, st)
+            call("cogaim_focal_weighted_colsum", S, ldS, N * ldS, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["attn"]), ptr(ws["part"]), B, N, st)
+            call("cogaim_focal_reduce_u", ptr(ws["part"]), ptr(ws["u"]), ptr(ws["usum"]), B, N, st)
+            call("cogaim_weighted_tokens", tok, tstride, s_in, ptr(pe), ptr(ws["u"]), ptr(ws["wt"]), B, N, D, st)
+            self._linear(ptr(ws["wt"]), D, pfx + "value_proj", ptr(ws["w"]), D, B, bias_scale=ws["usum"])
+            self._linear(ptr(ws["w"]), D, pfx + "projection.0", ptr(ws["t256"]), 256, B, act=1)
+            self._linear(ptr(ws["t256"]), 256, pfx + "projection.3", ws["feats"].data_ptr() + 64 * i * 4, 64 * I, B)
+        self._linear(ptr(ws["feats"]), 64 * I, "focal_stream.fusion.0", ptr(ws["t128"]), 128, B, act=1)
+        return ws["attn"]
+
+    def _focal_fused_into(self, ws, B, col):
+        self._linear(ptr(ws["t128"]), 128, "focal_stream.fusion.2", ws["cat"].data_ptr() + col * 4, 192, B)
+
+    def _check_fallback_flags(self, ws):
+        """The reference switches to other attention summaries when the whole-batch variance
+        of (column mean + centre bias) is below 1e-6 (src/model.py:242-257).  The predicate is
+        evaluated on device; it is impossible for any grid larger than 1x1 (the centre bias
+        alone has variance far above the threshold), so a set flag is reported, not emulated."""
+        if self.num_iterations and bool(ws["flags"][: self.num_iterations].any().item()):
+            if ws["N"] > 1:
+                raise RuntimeError("focal attention variance fell below 1e-6: the reference's degenerate-"
+                                   "attention fallbacks (src/model.py:242-257) are not built")
+
+    def _ambient(self, ws, B, col):
+        T, D = ws["T"], self.feature_dim
+        cls = ws["tokens"].data_ptr()                  # row b*T is the CLS token of image b
+        self._linear(cls, T * D, "ambient_stream.mlp.0", ptr(ws["t256"]), 256, B, act=1)
+        self._linear(ptr(ws["t256"]), 256, "ambient_stream.mlp.3", ptr(ws["t128"]), 128, B, act=1)
+        self._linear(ptr(ws["t128"]), 128, "ambient_stream.mlp.5", ws["cat"].data_ptr() + col * 4, 192, B)
+
+    def _exif_inputs(self, exif_data: dict, B: int):
+        """Validated device copies of the four EXIF vectors ([B] or [B,1], src/model.py:491-508)."""
+        dev = self._packed["device"]
+
+        def vec(k, dtype):
+            t = exif_data[k]
+            if t.dim() > 1:
+                t = t.squeeze(1)
+            t = t.to(device=dev, dtype=dtype).contiguous()
+            if t.numel() != B:
+                raise ValueError(f"exif_data['{k}'] has {t.numel()} entries for a batch of {B}")
+            return t
+        idx = vec("camera_idx", torch.int64)
+        n_cam = self._packed["f32"]["exif_prior.camera_embedding.weight"].shape[0]
+        if int(idx.min()) < 0 or int(idx.max()) >= n_cam:
+            raise IndexError("index out of range in self")
+        return idx, vec("focal_length", torch.float32), vec("aperture", torch.float32), vec("iso", torch.float32)
+
+    def _exif(self, exif_in, ws, B, col):
+        idx, fl, ap, iso = exif_in
+        emb = self._packed["f32"]["exif_prior.camera_embedding.weight"]
+        call("cogaim_exif_prep", ptr(idx), ptr(fl), ptr(ap), ptr(iso), ptr(emb), 64, ptr(ws["exf"]), 128,
+             ptr(ws["cont"]), B, stream_ptr())
+        self._linear(ptr(ws["cont"]), 3, "exif_prior.exif_encoder.0", ptr(ws["t64"]), 64, B, act=1)
+        self._linear(ptr(ws["t64"]), 64, "exif_prior.exif_encoder.2", ws["exf"].data_ptr() + 64 * 4, 128, B)
+        self._linear(ptr(ws["exf"]), 128, "exif_prior.fusion.0", ptr(ws["t256"]), 256, B, act=1)
+        self._linear(ptr(ws["t256"]), 256, "exif_prior.fusion.3", ws["cat"].data_ptr() + col * 4, 192, B)
+
+    def _heads(self, ws, B):
+        f = self._packed["f32"]
+        self._linear(ptr(ws["cat"]), 192, "fusion.0", ptr(ws["fused"]), 192, B, act=1)
+        out = torch.empty(2, B, device=self._packed["device"], dtype=torch.float32)
+        call("cogaim_heads", ptr(ws["fused"]), 192, ptr(f["decision_head.0.weight"]), ptr(f["decision_head.0.bias"]),
+             ptr(f["confidence_head.0.weight"]), ptr(f["confidence_head.0.bias"]),
+             ptr(f["confidence_head.2.weight"]), ptr(f["confidence_head.2.bias"]),
+             out.data_ptr(), out.data_ptr() + B * 4, B, stream_ptr())
+        return out[0].unsqueeze(1), out[1].unsqueeze(1)
+
+    def _prepare(self, images: torch.Tensor):
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in "
+                             f"the configuration. Expected 3 but got {images.shape[1] if images.dim() == 4 else '?'}.")
+        self._pack()
+        dev = self._packed["device"]
+        if images.device != dev:
+            raise RuntimeError(f"images are on {images.device}, model on {dev}")
+        images = images.to(torch.float32).contiguous()
+        B, _, Hi, Wi = images.shape
+        gh, gw = Hi // self.patch_size, Wi // self.patch_size
+        if gh < 1 or gw < 1:
+            raise ValueError("image smaller than one patch")
+        return images, self._workspace(B, gh, gw), B
+
+    # ------------------------------------------------------------------ reference API
+    @torch.no_grad()
+    def get_features_aligned(self, images, exif_data=None):
+        """Fused 192-d features (reference src/model.py:960-1056), one pass."""
+        images, ws, B = self._prepare(images)
+        self._features(images, exif_data, ws, B)
+        self._linear(ptr(ws["cat"]), 192, "fusion.0", ptr(ws["fused"]), 192, B, act=1)
+        self._check_fallback_flags(ws)
+        return ws["fused"].clone()
+
+    def _features(self, images, exif_data, ws, B, focal_override=None):
+        """Fills ws['cat'] with [ambient | focal | exif] (zero where a module is absent)."""
+        if not (self.use_ambient or self.use_focal or (self.use_exif and exif_data is not None)):
+            raise RuntimeError("Cognitive modules returned no features!")
+        exif_in = self._exif_inputs(exif_data, B) if (self.use_exif and exif_data is not None) else None
+        self._backbone(images, ws)
+        ws["cat"].zero_()
+        col = 0
+        if self.use_ambient:
+            self._ambient(ws, B, col)
+            col += 64
+        if self.use_focal:
+            self._focal(B, ws)
+            if focal_override is None:
+                self._focal_fused_into(ws, B, col)
+            else:
+                focal_override(col)
+            col += 64
+        if exif_in is not None:
+            self._exif(exif_in, ws, B, col)
+            col += 64
+        return col
+
+    def get_features(self, images, exif_data=None):
+        return self.get_features_aligned(images, exif_data)
+
+    def get_attention_weights(self):
+        return getattr(self, "_last_attention_weights", None)
+
+    @torch.no_grad()
+    def forward(self, images, exif_data=None, return_attention=False):
+        """(depth [B,1], confidence [B,1]) or (+ attention [B,N] | None)  — reference src/model.py:1064-1155."""
+        images, ws, B = self._prepare(images)
+        self._features(images, exif_data, ws, B)
+        depth, conf = self._heads(ws, B)
+        self._check_fallback_flags(ws)
+        self.fusion_features = ws["fused"].clone()
+        attn = ws["attn"].clone() if self.use_focal else None
+        if self.use_focal and not hasattr(self, "_last_attention_weights"):
+            self._last_attention_weights = attn          # :1093-1113
+        elif not self.use_focal:
+            self._last_attention_weights = None          # :1116-1117
+        if return_attention:
+            return depth, conf, attn
+        return depth, conf
+
+    @torch.no_grad()
+    def forward_with_guidance(self, images, exif_data=None, attention_guidance=None, return_attention=False,
+                              temp_projection: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """Instruction-guided forward (reference src/model.py:1157-1240).
+
+        ``temp_projection=(weight [64,768], bias [64])`` pins the Linear(768,64) that the
+        reference re-creates with fresh random weights on every guided call (:1417-1422);
+        when omitted a new ``nn.Linear(768, 64)`` is drawn from torch's global RNG exactly
+        as the reference does, so guided depth is as irreproducible here as it is there.
+        """
+        if not self.use_focal or attention_guidance is None:
+            if self.use_focal or self.use_ambient:
+                out = self.forward(images, exif_data, True)
+                if self.use_focal:
+                    self._last_attention_weights = out[2]
+                return out if return_attention else out[:2]
+            return self.forward(images, exif_data, return_attention)
+        images, ws, B = self._prepare(images)
+        N, D, T = ws["N"], self.feature_dim, ws["T"]
+        g = tables.guidance_vector(attention_guidance, N)
+        if g.numel() != N:
+            raise ValueError("attention_guidance cannot be resized to the patch grid")
+        gkey = ("mask", attention_guidance.lower(), math.isqrt(N)) if isinstance(attention_guidance, str) else None
+        gdev = self._table(*gkey) if gkey else g.to(self._packed["device"]).contiguous()
+        if temp_projection is None:
+            lin = nn.Linear(self.feature_dim, 64)
+            temp_projection = (lin.weight.detach(), lin.bias.detach())
+        pw = temp_projection[0].to(self._packed["device"], torch.float32).contiguous()
+        pb = temp_projection[1].to(self._packed["device"], torch.float32).contiguous()
+
+        def guided_focal(col):
+            st = stream_ptr()
+            call("cogaim_guided_attention", ptr(ws["attn"]), ptr(gdev), ptr(ws["guided"]), B, N, 0.7, 0.05, st)
+            call("cogaim_weighted_tokens", ws["tokens"].data_ptr() + D * 4, T * D, None, None, ptr(ws["guided"]),
+                 ptr(ws["wt"]), B, N, D, st)
+            self._linear(ptr(ws["wt"]), D, None, ws["cat"].data_ptr() + col * 4, 192, B, W=pw, bias=pb)
+
+        ncols = self._features(images, exif_data, ws, B, focal_override=guided_focal)
+        self._check_fallback_flags(ws)
+        attn = ws["guided"].clone()
+        self._last_attention_weights = attn                # :1212
+        if ncols != 192:
+            # the reference's fusion Linear(192,192) rejects the short concat and its except
+            # branch re-runs the standard forward (:1226, :1237-1240); the guided attention stays cached
+            out = self.forward(images, exif_data, return_attention)
+            return out
+        depth, conf = self._heads(ws, B)
+        if return_attention:
+            return depth, conf, attn
+        return depth, conf
+
+    # training-only helpers of the reference that callers may probe for
+    def compute_curiosity_loss(self, *a, **k):
+        raise NotImplementedError("training is out of scope for this build")
+
+    def get_exploration_stats(self):
+        return {"mean": 0.0, "std": 0.0, "max": 0.0, "samples": 0}
+
+
+def create_model(config, camera_info=None, device=None):
+    """Factory with the reference's signature (src/model.py:1534-1586), including the
+    optional top-level ``config['load_checkpoint']`` loader that skips head and
+    cognitive-module weights (:1549-1577)."""
+    model = CognitiveAimModel(config, camera_info)
+    if device is not None:
+        model = model.to(device)
+    if config.get("load_checkpoint"):
+        path = config["load_checkpoint"]
+        try:
+            state = torch.load(path, map_location="cpu", weights_only=True)
+            skip = ("decision_head.", "confidence_head.", "curiosity_module.", "global_aligner.",
+                    "ambient_stream.", "focal_stream.", "exif_prior.", "fusion.")
+            model.load_state_dict({k: v for k, v in state.items() if not k.startswith(skip)}, strict=False)
+            if device is not None:
+                model = model.to(device)
+        except Exception as e:  # same outward behaviour as the reference: warn and keep the init
+            print(f"Warning: Unable to load pretrained weights {path}: {e}")
+    return model.eval()

@@ -1,0 +1,138 @@
+/* C ABI of libcogaim.so: gfx950 (MI355X) kernels for the Cognitive-Aim depth
+ * forward pass.
+ *
+ * The reference (yenjane-dot/cognitive-aim-depth-estimation) is pure Python on
+ * stock ATen ops: it has no plugin / operator / FFI layer, so each entry point
+ * below names the reference ARITHMETIC it replaces (file:line; "hf:" =
+ * transformers/models/dinov2/modeling_dinov2.py, the un-vendored DINOv2
+ * dependency).  The Python side that keeps the reference's nn.Module API
+ * (create_model / forward / forward_with_guidance) binds these with ctypes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless stated; the caller owns all memory;
+ *  - `stream` is a hipStream_t (NULL = default stream); nothing here allocates,
+ *    synchronises or throws; launches are asynchronous;
+ *  - return 0 on success, -22 for an unsupported shape/argument, -1000-<hipError>
+ *    when the launch itself failed;
+ *  - `dtype` selects the 16-bit operand type: 0 = bf16, 1 = fp16 (accumulation is fp32);
+ *  - matrices are row-major; "16-bit [M,K]" operands are K-contiguous with a
+ *    leading dimension in ELEMENTS that is a multiple of 8.
+ */
+#ifndef COGAIM_H
+#define COGAIM_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int cogaim_version(void);
+
+/* ---- DINOv2 backbone --------------------------------------------------- */
+
+/* hf:139-149 Dinov2PatchEmbeddings (Conv2d k=14,s=14 as an im2col GEMM), step 1:
+ * images fp32 [B,3,H,W] -> cols 16-bit [B*(H/p)*(W/p), Kp], column = c*p*p + ky*p + kx,
+ * zero-padded from 3*p*p to Kp (multiple of 64). */
+int cogaim_im2col(const float* images, void* cols, int B, int H, int W, int patch, int Kp, int dtype, void* stream);
+
+/* hf:97-116 Dinov2Embeddings, step 2: x[b, 1+p, :] = cols[b*P+p] . W^T + bias + pos[1+p]
+ * (x fp32 [B, P+1, D], W 16-bit [D, Kp], pos fp32 [P+1, D] already interpolated, hf:57-95). */
+int cogaim_gemm_patch_embed(const void* cols, const void* W, const float* bias, const float* pos, float* x, int B,
+                            int P, int D, int K, int dtype, void* stream);
+
+/* hf:108-112: x[b, 0, :] = cls_token + pos[0]. */
+int cogaim_cls_row(const float* cls, const float* pos, float* x, int B, int T, int D, void* stream);
+
+/* hf:348,353,441 nn.LayerNorm(D, eps): out = LN(x) * gamma + beta.  x fp32 [M,D];
+ * out_dtype 0 bf16, 1 fp16, 2 fp32. */
+int cogaim_layernorm(const float* x, const float* gamma, const float* beta, void* out, int M, int D, float eps,
+                     int out_dtype, void* stream);
+
+/* hf:199-213 query/key Linear (one fused GEMM): out16[M,N] = A . W^T + bias, and columns
+ * [0, scale_cols) times `scale` (the softmax scale hf:196 folded into Q).  Also the focal
+ * stream's query_proj/key_proj (src/model.py:192-193, scale 1/sqrt(D//8) of :69,197). */
+int cogaim_gemm_bias_half(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int lda,
+                          int ldw, int ldc, int scale_cols, float scale, int dtype, void* stream);
+
+/* hf:201,212 value Linear, written transposed per head for the attention kernel:
+ * vt[(b*H+h)*64 + d][t] = A[b*T+t] . W[h*64+d] + bias[h*64+d];  rows are Tp long (Tp >= T, multiple of 64);
+ * columns t >= T are never written and must be finite (zero them once). */
+int cogaim_gemm_vt(const void* A, const void* W, const float* bias, void* vt, int B, int T, int D, int K, int lda,
+                   int ldw, int Tp, int dtype, void* stream);
+
+/* hf:153-178 softmax(Q K^T * dh^-0.5) V for all heads (dh = 64), flash style.
+ * qk 16-bit [B*T, ldqk]: Q pre-multiplied by dh^-0.5*log2(e) in cols [0,D), K in [D,2D);
+ * vt as written by cogaim_gemm_vt; ctx 16-bit [B*T, D]. */
+int cogaim_mhsa_fwd(const void* qk, const void* vt, void* ctx, int B, int T, int H, int Tp, int ldqk, int dtype,
+                    void* stream);
+
+/* hf:246-252 output dense + hf:277-278 LayerScale + hf:370 residual, and the same for
+ * fc2 (hf:296, 375-378):  x[M,N] += (A . W^T + bias) * layerscale, in place, x fp32. */
+int cogaim_gemm_residual_f32(const void* A, const void* W, const float* bias, const float* layerscale, float* x, int M,
+                             int N, int K, int lda, int ldw, int ldc, int dtype, void* stream);
+
+/* hf:293-295 fc1 + exact (erf) GELU: out16[M,N] = gelu(A . W^T + bias). */
+int cogaim_gemm_bias_gelu_half(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int lda,
+                               int ldw, int ldc, int dtype, void* stream);
+
+/* ---- focal stream (src/model.py:128-313, 391-455) ----------------------- */
+
+/* :184 patch_tokens + pos_encoding, with the iteration rescale of :426 folded in:
+ * out16[b*N+n] = tok[b][n] * scale[b][n] + pe[n]   (scale may be NULL). */
+int cogaim_focal_prep(const float* tok, long long tok_stride_b, const float* scale, const float* pe, void* out, int B,
+                      int N, int D, int dtype, void* stream);
+
+/* :197 attention_scores = Q K^T / scale, per image: out32[z] = A[z] . W[z]^T (strides in elements). */
+int cogaim_gemm_batched_f32(const void* A, const void* W, float* out, int M, int N, int K, int lda, int ldw, int ldc,
+                            long long strideA, long long strideW, long long strideC, int batch, int dtype,
+                            void* stream);
+
+/* rows per partial block of the two column-sum kernels below */
+int cogaim_focal_colsum_rows(void);
+
+/* :200 softmax row statistics (scores in the log2 domain) and :234 attention_weights.mean(dim=1):
+ * rmax/rinv [B,N]; part [B, nblk, N] = per-row-block column sums of the softmax. */
+int cogaim_focal_softmax_stats_colsum(const float* S, int ldS, long long strideS, float* rmax, float* rinv, float* part,
+                                      int B, int N, void* stream);
+
+/* :239-282 centre bias, L1 normalise, clamp, renormalise -> a[B,N]; also :426 next-iteration token scale. */
+int cogaim_focal_attention_vector(const float* part, const float* center_bias, float* a, double* stats,
+                                  const float* scale_in, float* scale_out, float focus_strength, int B, int N,
+                                  void* stream);
+
+/* :242 `patch_attention.var() < 1e-6` over the whole batch, evaluated on device into flags[slot]. */
+int cogaim_focal_var_flag(const double* stats, int B, int N, int* flags, int slot, void* stream);
+
+/* :204,:308  sum_n a_n (P V)_n = (a^T P) V:  part[b][blk][c] = sum_{n in blk} roww[b][n] P[b][n][c]. */
+int cogaim_focal_weighted_colsum(const float* S, int ldS, long long strideS, const float* rmax, const float* rinv,
+                                 const float* roww, float* part, int B, int N, void* stream);
+int cogaim_focal_reduce_u(const float* part, float* u, float* usum, int B, int N, void* stream);
+
+/* out[b][:] = sum_n w[b][n] * (tok[b][n][:] * scale[b][n] + pe[n][:]);  scale/pe NULL = 1/0.
+ * Used for (a^T P) Xt above and for the guided token sum of src/model.py:1412-1414. */
+int cogaim_weighted_tokens(const float* tok, long long tok_stride_b, const float* scale, const float* pe, const float* w,
+                           float* out, int B, int N, int D, void* stream);
+
+/* src/model.py:1401-1409: out = softmax((alpha*mask + (1-alpha)*a) / temperature). */
+int cogaim_guided_attention(const float* a, const float* mask, float* out, int B, int N, float alpha, float temperature,
+                            void* stream);
+
+/* ---- per-image MLPs and heads ------------------------------------------- */
+
+/* nn.Linear (+ReLU) in fp32 for the ambient MLP (src/model.py:37-44), focal projection (:82-87),
+ * focal fusion (:342-346), EXIF MLPs (:468-480), fusion (:908-912):
+ * out[b*ldo+o] = act(x[b*ldx+:K] . W[o] + bias[o]*bias_scale[b]);  act 0 none, 1 ReLU. */
+int cogaim_linear_f32(const float* x, int ldx, const float* W, const float* bias, const float* bias_scale, float* out,
+                      int ldo, int B, int O, int K, int act, void* stream);
+
+/* src/model.py:491-514: camera embedding gather and [focal_length, aperture, log(iso+1)]. */
+int cogaim_exif_prep(const long long* camera_idx, const float* focal_length, const float* aperture, const float* iso,
+                     const float* embedding, int emb_dim, float* feat, int ldf, float* cont, int B, void* stream);
+
+/* src/model.py:925-941,1120-1123: depth = Softplus(Linear), conf = Sigmoid(Linear(1,1)(ReLU(Linear))). */
+int cogaim_heads(const float* fused, int K, const float* wd, const float* bd, const float* wc, const float* bc,
+                 const float* w2, const float* b2, float* depth, float* conf, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COGAIM_H */

@@ -1,0 +1,266 @@
+"""Generate tests/golden/*.npz by running the REAL reference.  Build-container only.
+
+Path-loads /root/reference/src/model.py (``import src.model`` would drag in
+torchvision through src/__init__.py:4), replaces the hub fetch
+``Dinov2Model.from_pretrained('facebook/dinov2-base')`` (src/model.py:814) by
+a local random-init ``Dinov2Model(Dinov2Config(...))``, runs the reference on
+seeded inputs and stores inputs + outputs (+ weights when they are small).
+Nothing from the reference is copied: the fixtures are data only.
+
+    python oracle/make_goldens.py            # rewrites tests/golden/
+"""
+from __future__ import annotations
+
+import contextlib
+import importlib.util
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+os.environ.setdefault("HF_HUB_OFFLINE", "1")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.weights import reference_state_spec, synth_state_dict  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference/src/model.py"
+
+
+def load_reference():
+    spec = importlib.util.spec_from_file_location("ref_model", REF)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        yield buf
+
+
+def npd(sd, prefix="w:"):
+    return {prefix + k: v.detach().numpy() for k, v in sd.items()}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def g1_tiny_backbone(ref):
+    from transformers import Dinov2Config, Dinov2Model
+    torch.manual_seed(0)
+    cfg = Dinov2Config(hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+                       image_size=56, patch_size=14)
+    model = Dinov2Model(cfg).eval()
+    # HF init (std 0.02) gives near-uniform attention; widen q/k so softmax is exercised.
+    with torch.no_grad():
+        for layer in model.encoder.layer:
+            layer.attention.attention.query.weight.mul_(8.0)
+            layer.attention.attention.key.weight.mul_(8.0)
+            layer.layer_scale1.lambda1.add_(0.1 * torch.randn(64))
+            layer.norm1.bias.add_(0.1 * torch.randn(64))
+    arrays = npd(model.state_dict())
+    for size in (56, 70, 98):
+        x = torch.randn(2, 3, size, size)
+        with torch.no_grad():
+            y = model(x, output_hidden_states=True).last_hidden_state
+        arrays[f"x{size}"] = x.numpy()
+        arrays[f"y{size}"] = y.numpy()
+    save("g1_tiny_backbone", **arrays)
+
+
+def g2_focal(ref):
+    arrays = {}
+    torch.manual_seed(1)
+    for tag, dim, n in (("a", 64, 16), ("b", 64, 25), ("c", 64, 20), ("d", 128, 49)):
+        fs = ref.FocalStream(dim, curiosity_guided=False).eval()
+        x = torch.randn(2, n, dim)
+        captured = {}
+        hook = fs.query_proj.register_forward_pre_hook(
+            lambda mod, inp: captured.__setitem__("xt", inp[0].detach().clone()))
+        with torch.no_grad(), quiet():
+            f, a = fs(x)
+        hook.remove()
+        arrays.update(npd(fs.state_dict(), f"{tag}:w:"))
+        arrays[f"{tag}:x"] = x.numpy()
+        arrays[f"{tag}:f"] = f.numpy()
+        arrays[f"{tag}:a"] = a.numpy()
+        arrays[f"{tag}:pe"] = (captured["xt"] - x)[0].numpy()
+    save("g2_focal_stream", **arrays)
+
+
+def g3_iterative(ref):
+    arrays = {}
+    torch.manual_seed(2)
+    for tag, iters, fstr, n in (("a", 2, 0.1, 16), ("b", 3, 1.5, 25), ("c", 8, 1.5, 16)):
+        it = ref.IterativeFocalStream(64, num_iterations=iters, curiosity_guided=False,
+                                      focus_strength=fstr).eval()
+        x = torch.randn(2, n, 64)
+        with torch.no_grad(), quiet():
+            f, a = it(x)
+        arrays.update(npd(it.state_dict(), f"{tag}:w:"))
+        arrays[f"{tag}:x"] = x.numpy()
+        arrays[f"{tag}:f"] = f.numpy()
+        arrays[f"{tag}:a"] = a.numpy()
+        arrays[f"{tag}:iters"] = iters
+        arrays[f"{tag}:fs"] = fstr
+    save("g3_iterative_focal", **arrays)
+
+
+def g5_guidance(ref):
+    """Masks and guided softmax straight from CognitiveAimModel._guided_focal_stream
+    driven with a stand-in ``self`` (only focal_stream / feature_dim are touched)."""
+    arrays = {}
+    torch.manual_seed(3)
+    names = ["center", "left", "right", "top", "bottom", "top-left", "top-right",
+             "bottom-left", "bottom-right", "topleft", "TopRight", "bottomleft",
+             "BOTTOMRIGHT", "Center", "somewhere-else"]
+
+    class Stub:
+        feature_dim = 4
+
+    for g in (4, 5, 16, 37):
+        n = g * g
+        base = torch.rand(2, n)
+        base = base / base.sum(-1, keepdim=True)
+        stub = Stub()
+        stub.focal_stream = lambda p, c, _b=base: (torch.zeros(2, 64), _b)
+        patches = torch.randn(2, n, 4)
+        arrays[f"g{g}:base"] = base.numpy()
+        for name in names:
+            with torch.no_grad(), quiet():
+                _, att = ref.CognitiveAimModel._guided_focal_stream(stub, patches, None, name)
+            arrays[f"g{g}:{name}"] = att.numpy()
+        gt = torch.rand(196)
+        with torch.no_grad(), quiet():
+            _, att = ref.CognitiveAimModel._guided_focal_stream(stub, patches, None, gt)
+        arrays[f"g{g}:tensor196_in"] = gt.numpy()
+        arrays[f"g{g}:tensor196"] = att.numpy()
+    save("g5_guidance", **arrays)
+
+
+def g6_pe_table(ref):
+    """Sub-sampled rows of the full-size position table (N=1369, D=768)."""
+    fs = ref.FocalStream(768, curiosity_guided=False).eval()
+    arrays = {}
+    for n in (256, 1369):
+        x = torch.zeros(1, n, 768)
+        captured = {}
+        hook = fs.query_proj.register_forward_pre_hook(
+            lambda mod, inp: captured.__setitem__("xt", inp[0].detach().clone()))
+        with torch.no_grad(), quiet():
+            fs(x)
+        hook.remove()
+        pe = captured["xt"][0]
+        rows = sorted({0, 1, int(n ** 0.5) - 1, int(n ** 0.5), n // 2, n - 1})
+        arrays[f"n{n}:rows"] = np.array(rows)
+        arrays[f"n{n}:pe_rows"] = pe[rows].numpy()
+        arrays[f"n{n}:colsum"] = pe.double().sum(0).numpy()
+        arrays[f"n{n}:rowsum"] = pe.double().sum(1).numpy()
+    save("g6_pe_table", **arrays)
+
+
+def g7_full_model(ref):
+    """Full-width model, 2-layer backbone, native 4x4 grid, synthetic weights
+    regenerated from (seed, key) by oracle/weights.py."""
+    from transformers import Dinov2Config, Dinov2Model
+    layers, grid = 2, 4
+    ref.Dinov2Model.from_pretrained = classmethod(
+        lambda cls, name, *a, **k: Dinov2Model(Dinov2Config(image_size=14 * grid,
+                                                            num_hidden_layers=layers)))
+    arrays = {"layers": layers, "native_grid": grid, "seed": 7}
+    for tag, cam, iters in (("full", {"num_cameras": 71}, 3), ("noexif", None, 3),
+                            ("it2", {"num_cameras": 71}, 2)):
+        cfg = {"cognitive_modules": ["ambient_stream", "iterative_focal_stream",
+                                     "exif_prior_database"],
+               "focal_config": {"num_iterations": iters,
+                                "focus_strength": 1.5 if iters == 3 else 0.4}}
+        with quiet():
+            model = ref.create_model(cfg, cam).eval()
+        spec = reference_state_spec(layers=layers, native_grid=grid, num_iterations=iters,
+                                    num_cameras=71 if cam else 0)
+        ref_sd = model.state_dict()
+        assert list(ref_sd.keys()) == list(spec.keys()), \
+            (set(ref_sd) ^ set(spec))
+        for k, (shp, dt) in spec.items():
+            assert tuple(ref_sd[k].shape) == tuple(shp) and ref_sd[k].dtype == dt, k
+        sd = synth_state_dict(spec, seed=7)
+        model.load_state_dict(sd, strict=True)
+        for size in ((56, 70, 224) if tag == "full" else (56,)):
+            torch.manual_seed(100 + size)
+            x = torch.randn(2, 3, size, size)
+            exif = {"camera_idx": torch.tensor([0, 5]),
+                    "focal_length": torch.tensor([50.0, 24.0]),
+                    "aperture": torch.tensor([2.8, 8.0]),
+                    "iso": torch.tensor([100.0, 1600.0])}
+            key = f"{tag}:{size}"
+            arrays[key + ":x"] = x.numpy()
+            for k, v in exif.items():
+                arrays[f"{key}:exif:{k}"] = v.numpy()
+            if hasattr(model, "_last_attention_weights"):
+                delattr(model, "_last_attention_weights")
+            with torch.no_grad(), quiet() as log:
+                d, c, a = model(x, exif if cam else None, return_attention=True)
+            assert "exception" not in log.getvalue(), log.getvalue()
+            arrays[key + ":depth"], arrays[key + ":conf"], arrays[key + ":attn"] = \
+                d.numpy(), c.numpy(), a.numpy()
+            if tag != "full":
+                continue
+            # [B,1]-shaped EXIF must give the same answer (src/model.py:492-508)
+            exif2 = {k: v.unsqueeze(1) for k, v in exif.items()}
+            with torch.no_grad(), quiet():
+                d2, c2 = model(x, exif2)
+            assert torch.equal(d2, d) and torch.equal(c2, c)
+            # exif omitted -> zero-pad branch (src/model.py:1035-1039)
+            with torch.no_grad(), quiet():
+                d3, c3 = model(x, None)
+            arrays[key + ":depth_noexif"], arrays[key + ":conf_noexif"] = d3.numpy(), c3.numpy()
+            # guided path: attention for every instruction; depth for 'center'
+            # with the per-call random projection captured (src/model.py:1417-1422)
+            for name in ("center", "left", "right", "top", "bottom", "top-left",
+                         "top-right", "bottom-left", "bottom-right"):
+                created = []
+                real_linear = ref.nn.Linear
+
+                class Spy(real_linear):
+                    def __init__(self, *a, **k):
+                        super().__init__(*a, **k)
+                        created.append(self)
+
+                ref.nn.Linear = Spy
+                try:
+                    with torch.no_grad(), quiet() as log:
+                        gd, gc, ga = model.forward_with_guidance(x, exif, name,
+                                                                 return_attention=True)
+                finally:
+                    ref.nn.Linear = real_linear
+                assert "failed" not in log.getvalue(), log.getvalue()
+                arrays[f"{key}:guided:{name}"] = ga.numpy()
+                if name == "center" and size == 56:
+                    assert len(created) == 1
+                    arrays[key + ":guided_proj_w"] = created[0].weight.detach().numpy()
+                    arrays[key + ":guided_proj_b"] = created[0].bias.detach().numpy()
+                    arrays[key + ":guided_depth"] = gd.numpy()
+                    arrays[key + ":guided_conf"] = gc.numpy()
+    save("g7_full_model", **arrays)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = load_reference()
+    g1_tiny_backbone(ref)
+    g2_focal(ref)
+    g3_iterative(ref)
+    g5_guidance(ref)
+    g6_pe_table(ref)
+    g7_full_model(ref)
+
+
+if __name__ == "__main__":
+    main()

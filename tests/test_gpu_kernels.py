@@ -1,0 +1,204 @@
+"""Kernel-level parity through the C ABI (ctypes), each against a plain fp32
+PyTorch statement of the same operation on the SAME rounded 16-bit operands."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cognitive_aim_depth_estimation_amd._lib import call, ptr, stream_ptr  # noqa: E402
+
+DT = {"bf16": (0, torch.bfloat16), "fp16": (1, torch.float16)}
+LOG2E = 1.4426950408889634
+
+
+@pytest.fixture(autouse=True)
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    torch.manual_seed(0)
+    yield
+    torch.cuda.synchronize()
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0):
+    return (torch.randn(*shape, device="cuda") * scale).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 64), (1370 * 2 + 1, 1536, 768), (64, 128, 3072), (129, 64, 128)])
+def test_gemm_bias_half(dtype, M, N, K):
+    di, tdt = DT[dtype]
+    A, W, bias = rnd(M, K, dtype=tdt), rnd(N, K, dtype=tdt, scale=K ** -0.5), rnd(N)
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=tdt)
+    call("cogaim_gemm_bias_half", ptr(A), ptr(W), ptr(bias), ptr(out), M, N, K, K, K, N, N // 2, 0.25, di, stream_ptr())
+    ref = A.float() @ W.float().t() + bias
+    ref[:, : N // 2] *= 0.25
+    tol = 2 ** -8 if dtype == "bf16" else 2 ** -10
+    assert torch.allclose(out.float(), ref, rtol=tol, atol=tol), float((out.float() - ref).abs().max())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_gemm_residual_and_gelu(dtype):
+    di, tdt = DT[dtype]
+    M, N, K = 1000, 768, 3072
+    A, W, bias, ls = rnd(M, K, dtype=tdt), rnd(N, K, dtype=tdt, scale=K ** -0.5), rnd(N), 1 + 0.1 * rnd(N)
+    x0 = rnd(M, N)
+    x = x0.clone()
+    call("cogaim_gemm_residual_f32", ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(x), M, N, K, K, K, N, di, stream_ptr())
+    ref = x0 + (A.float() @ W.float().t() + bias) * ls
+    assert torch.allclose(x, ref, rtol=1e-4, atol=1e-4), float((x - ref).abs().max())
+    M, N, K = 515, 3072, 768
+    A, W, bias = rnd(M, K, dtype=tdt), rnd(N, K, dtype=tdt, scale=K ** -0.5), rnd(N)
+    out = torch.empty(M, N, device="cuda", dtype=tdt)
+    call("cogaim_gemm_bias_gelu_half", ptr(A), ptr(W), ptr(bias), ptr(out), M, N, K, K, K, N, di, stream_ptr())
+    ref = torch.nn.functional.gelu(A.float() @ W.float().t() + bias)
+    tol = 2 ** -8 if dtype == "bf16" else 2 ** -10
+    assert torch.allclose(out.float(), ref, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("N", [100, 1369])
+def test_gemm_batched_scores(dtype, N):
+    di, tdt = DT[dtype]
+    B, D = 3, 768
+    ldS = (N + 127) // 128 * 128
+    qk = rnd(B * N, 2 * D, dtype=tdt, scale=0.5)
+    S = torch.zeros(B, N, ldS, device="cuda")
+    call("cogaim_gemm_batched_f32", ptr(qk), qk.data_ptr() + D * 2, ptr(S), N, N, D, 2 * D, 2 * D, ldS,
+         N * 2 * D, N * 2 * D, N * ldS, B, di, stream_ptr())
+    q = qk.view(B, N, 2 * D)[:, :, :D].float()
+    k = qk.view(B, N, 2 * D)[:, :, D:].float()
+    ref = q @ k.transpose(1, 2)
+    assert torch.allclose(S[:, :, :N], ref, rtol=1e-4, atol=1e-3), float((S[:, :, :N] - ref).abs().max())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,T", [(2, 17), (3, 257), (2, 1370)])
+def test_gemm_vt(dtype, B, T):
+    di, tdt = DT[dtype]
+    D, H = 128, 2
+    Tp = (T + 63) // 64 * 64
+    A, W, bias = rnd(B * T, D, dtype=tdt), rnd(D, D, dtype=tdt, scale=D ** -0.5), rnd(D)
+    vt = torch.zeros(B * H * 64 * Tp, device="cuda", dtype=tdt)
+    call("cogaim_gemm_vt", ptr(A), ptr(W), ptr(bias), ptr(vt), B, T, D, D, D, D, Tp, di, stream_ptr())
+    ref = (A.float() @ W.float().t() + bias).view(B, T, H, 64).permute(0, 2, 3, 1)   # [B,H,64,T]
+    got = vt.view(B, H, 64, Tp)
+    tol = 2 ** -8 if dtype == "bf16" else 2 ** -10
+    assert torch.allclose(got[..., :T].float(), ref, rtol=tol, atol=tol)
+    assert torch.count_nonzero(got[..., T:]) == 0
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("size", [56, 70])
+def test_patch_embed(dtype, size):
+    di, tdt = DT[dtype]
+    B, D, p = 2, 128, 14
+    g = size // p
+    P, T = g * g, g * g + 1
+    img = rnd(B, 3, size, size)
+    w, bias, pos, cls = rnd(D, 3, p, p, scale=588 ** -0.5), rnd(D), rnd(T, D), rnd(D)
+    Kp = 640
+    wp = torch.zeros(D, Kp, device="cuda", dtype=tdt)
+    wp[:, :588] = w.reshape(D, -1).to(tdt)
+    cols = torch.empty(B * P, Kp, device="cuda", dtype=tdt)
+    x = torch.full((B, T, D), float("nan"), device="cuda")
+    call("cogaim_im2col", ptr(img), ptr(cols), B, size, size, p, Kp, di, stream_ptr())
+    call("cogaim_cls_row", ptr(cls), ptr(pos), ptr(x), B, T, D, stream_ptr())
+    call("cogaim_gemm_patch_embed", ptr(cols), ptr(wp), ptr(bias), ptr(pos), ptr(x), B, P, D, Kp, di, stream_ptr())
+    conv = torch.nn.functional.conv2d(img.to(tdt).float(), w.to(tdt).float(), bias, stride=p).flatten(2).transpose(1, 2)
+    ref = torch.cat([cls.expand(B, 1, D), conv], 1) + pos
+    assert torch.allclose(x, ref, rtol=1e-4, atol=1e-4), float((x - ref).abs().max())
+
+
+@pytest.mark.parametrize("out", [0, 1, 2])
+@pytest.mark.parametrize("M,D", [(7, 768), (1001, 768), (33, 64), (5, 1024)])
+def test_layernorm(out, M, D):
+    x = rnd(M, D) * 3 + 0.5
+    g, b = 1 + 0.1 * rnd(D), 0.1 * rnd(D)
+    tdt = [torch.bfloat16, torch.float16, torch.float32][out]
+    y = torch.empty(M, D, device="cuda", dtype=tdt)
+    call("cogaim_layernorm", ptr(x), ptr(g), ptr(b), ptr(y), M, D, 1e-6, out, stream_ptr())
+    ref = torch.nn.functional.layer_norm(x, (D,), g, b, 1e-6)
+    tol = [2 ** -8, 2 ** -10, 1e-5][out]
+    assert torch.allclose(y.float(), ref, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,T,H", [(2, 17, 2), (1, 64, 1), (2, 257, 3), (2, 1370, 12), (1, 130, 2)])
+def test_mhsa(dtype, B, T, H):
+    di, tdt = DT[dtype]
+    D = 64 * H
+    Tp = (T + 63) // 64 * 64
+    q, k, v = rnd(B, T, H, 64), rnd(B, T, H, 64), rnd(B, T, H, 64)
+    qk = torch.cat([(q * (64 ** -0.5 * LOG2E)).reshape(B * T, D), k.reshape(B * T, D)], 1).to(tdt).contiguous()
+    vt = torch.zeros(B, H, 64, Tp, device="cuda", dtype=tdt)
+    vt[..., :T] = v.permute(0, 2, 3, 1).to(tdt)
+    ctx = torch.full((B * T, D), float("nan"), device="cuda", dtype=tdt)
+    call("cogaim_mhsa_fwd", ptr(qk), ptr(vt), ptr(ctx), B, T, H, Tp, 2 * D, di, stream_ptr())
+    qr = qk[:, :D].float().view(B, T, H, 64).transpose(1, 2) / LOG2E
+    kr = qk[:, D:].float().view(B, T, H, 64).transpose(1, 2)
+    vr = vt[..., :T].float().transpose(2, 3)
+    ref = (torch.softmax(qr @ kr.transpose(2, 3), -1) @ vr).transpose(1, 2).reshape(B * T, D)
+    tol = 2 ** -7 if dtype == "bf16" else 2 ** -9      # P is rounded to 16 bit before P.V
+    assert torch.allclose(ctx.float(), ref, rtol=tol, atol=tol), float((ctx.float() - ref).abs().max())
+
+
+def test_mhsa_spike_rescale():
+    """One key that dominates a late tile forces the running-max rescale branch."""
+    di, tdt = DT["fp16"]
+    B, T, H, D = 1, 300, 1, 64
+    Tp = 320
+    q, k, v = rnd(B, T, H, 64), rnd(B, T, H, 64), rnd(B, T, H, 64)
+    k[0, 200] = q[0, 5] * 6          # query 5 meets a huge key in the 4th tile
+    qk = torch.cat([(q * (64 ** -0.5 * LOG2E)).reshape(T, D), k.reshape(T, D)], 1).to(tdt).contiguous()
+    vt = torch.zeros(B, H, 64, Tp, device="cuda", dtype=tdt)
+    vt[..., :T] = v.permute(0, 2, 3, 1).to(tdt)
+    ctx = torch.empty(T, D, device="cuda", dtype=tdt)
+    call("cogaim_mhsa_fwd", ptr(qk), ptr(vt), ptr(ctx), B, T, H, Tp, 2 * D, di, stream_ptr())
+    qr, kr = qk[:, :D].double() / LOG2E, qk[:, D:].double()
+    ref = torch.softmax(qr @ kr.t(), -1) @ vt[0, 0, :, :T].double().t()
+    assert torch.allclose(ctx.double(), ref, rtol=2 ** -9, atol=2 ** -9)
+
+
+def test_small_kernels():
+    B = 5
+    x, W, b, bs = rnd(B, 768), rnd(256, 768, scale=768 ** -0.5), rnd(256), rnd(B)
+    out = torch.zeros(B, 300, device="cuda")
+    call("cogaim_linear_f32", ptr(x), 768, ptr(W), ptr(b), ptr(bs), out.data_ptr() + 16 * 4, 300, B, 256, 768, 1, stream_ptr())
+    ref = torch.relu(x @ W.t() + b[None] * bs[:, None])
+    assert torch.allclose(out[:, 16:272], ref, rtol=1e-5, atol=1e-5)
+    assert torch.count_nonzero(out[:, :16]) == 0 and torch.count_nonzero(out[:, 272:]) == 0
+    x3, W3 = rnd(B, 3), rnd(64, 3)
+    o3 = torch.empty(B, 64, device="cuda")
+    call("cogaim_linear_f32", ptr(x3), 3, ptr(W3), None, None, ptr(o3), 64, B, 64, 3, 0, stream_ptr())
+    assert torch.allclose(o3, x3 @ W3.t(), rtol=1e-5, atol=1e-6)
+    # heads
+    f, wd, bd, wc, bc, w2, b2 = rnd(B, 192), rnd(1, 192, scale=0.1), rnd(1) + 1, rnd(1, 192, scale=0.1), rnd(1), rnd(1, 1), rnd(1)
+    f[0] *= 40       # exercises the softplus threshold (x > 20 -> x)
+    dc = torch.empty(2, B, device="cuda")
+    call("cogaim_heads", ptr(f), 192, ptr(wd), ptr(bd), ptr(wc), ptr(bc), ptr(w2), ptr(b2), dc.data_ptr(), dc.data_ptr() + B * 4, B, stream_ptr())
+    assert torch.allclose(dc[0], torch.nn.functional.softplus(f @ wd.t() + bd).squeeze(1), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(dc[1], torch.sigmoid(torch.relu(f @ wc.t() + bc) * w2[0, 0] + b2).squeeze(1), rtol=1e-5, atol=1e-6)
+    # exif prep
+    idx = torch.tensor([0, 70, 3, 3, 12], device="cuda")
+    fl, ap, iso = rnd(B).abs() * 50, rnd(B).abs() * 4, rnd(B).abs() * 800
+    emb = rnd(71, 64)
+    feat, cont = torch.zeros(B, 128, device="cuda"), torch.zeros(B, 3, device="cuda")
+    call("cogaim_exif_prep", ptr(idx), ptr(fl), ptr(ap), ptr(iso), ptr(emb), 64, ptr(feat), 128, ptr(cont), B, stream_ptr())
+    assert torch.equal(feat[:, :64], emb[idx])
+    assert torch.allclose(cont, torch.stack([fl, ap, torch.log(iso + 1)], 1), rtol=1e-6)
+
+
+@pytest.mark.parametrize("N", [16, 1369])
+def test_guided_attention_kernel(N):
+    from oracle import cogaim_oracle as O
+    B = 3
+    a = torch.rand(B, N, device="cuda")
+    a = a / a.sum(-1, keepdim=True)
+    for name in O.INSTRUCTIONS:
+        mask = O.guidance_mask(name, int(math.isqrt(N))).cuda()
+        out = torch.empty(B, N, device="cuda")
+        call("cogaim_guided_attention", ptr(a), ptr(mask), ptr(out), B, N, 0.7, 0.05, stream_ptr())
+        ref = O.guided_attention(a.cpu(), mask.cpu())
+        assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=1e-10)

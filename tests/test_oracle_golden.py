@@ -1,0 +1,145 @@
+"""The oracle against the golden vectors produced by the real reference
+(oracle/make_goldens.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cogaim_oracle as O
+from oracle.weights import reference_state_spec, synth_state_dict
+
+torch.set_grad_enabled(False)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def sd_from(z, prefix):
+    return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = torch.as_tensor(a)
+    b = torch.as_tensor(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), float((a - b).abs().max())
+
+
+def test_tiny_backbone(golden_dir):
+    z = load(golden_dir, "g1_tiny_backbone")
+    sd = sd_from(z, "w:")
+    sd = {"backbone." + k: v for k, v in sd.items()}
+    for size in (56, 70, 98):   # native grid, bicubic up-sampled 5x5 and 7x7
+        y = O.dinov2_forward(sd, torch.from_numpy(z[f"x{size}"]), n_heads=4)
+        close(y, z[f"y{size}"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_focal_stream(golden_dir, tag):
+    z = load(golden_dir, "g2_focal_stream")
+    sd = sd_from(z, f"{tag}:w:")
+    x = torch.from_numpy(z[f"{tag}:x"])
+    f, a = O.focal_stream(sd, "", x)
+    close(f, z[f"{tag}:f"], rtol=1e-4, atol=1e-6)
+    close(a, z[f"{tag}:a"], rtol=1e-4, atol=1e-8)
+    close(O.pe2d_table(x.shape[1], x.shape[2]), z[f"{tag}:pe"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_iterative_focal(golden_dir, tag):
+    z = load(golden_dir, "g3_iterative_focal")
+    sd = sd_from(z, f"{tag}:w:")
+    f, a = O.iterative_focal_stream(sd, torch.from_numpy(z[f"{tag}:x"]),
+                                    int(z[f"{tag}:iters"]), float(z[f"{tag}:fs"]), prefix="")
+    close(f, z[f"{tag}:f"], rtol=1e-4, atol=1e-6)
+    close(a, z[f"{tag}:a"], rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("g", [4, 5, 16, 37])
+def test_guidance(golden_dir, g):
+    z = load(golden_dir, "g5_guidance")
+    base = torch.from_numpy(z[f"g{g}:base"])
+    names = [k.split(":", 1)[1] for k in z.files
+             if k.startswith(f"g{g}:") and k.split(":", 1)[1] not in
+             ("base", "tensor196", "tensor196_in")]
+    assert len(names) == 15
+    for name in names:
+        att = O.guided_attention(base, O.resolve_guidance(name, g * g))
+        close(att, z[f"g{g}:{name}"], rtol=1e-4, atol=1e-9)
+    att = O.guided_attention(base, O.resolve_guidance(torch.from_numpy(z[f"g{g}:tensor196_in"]), g * g))
+    close(att, z[f"g{g}:tensor196"], rtol=1e-4, atol=1e-9)
+
+
+def test_pe_table_full_size(golden_dir):
+    z = load(golden_dir, "g6_pe_table")
+    for n in (256, 1369):
+        pe = O.pe2d_table(n, 768)
+        close(pe[torch.from_numpy(z[f"n{n}:rows"])], z[f"n{n}:pe_rows"], rtol=0, atol=1e-6)
+        close(pe.double().sum(0), z[f"n{n}:colsum"], rtol=0, atol=1e-4)
+        close(pe.double().sum(1), z[f"n{n}:rowsum"], rtol=0, atol=1e-4)
+        close(O._pe2d_table_loop(n, 768)[:40], pe[:40], rtol=0, atol=1e-6)
+
+
+def _full_sd(z, iters=3, cams=71):
+    spec = reference_state_spec(layers=int(z["layers"]), native_grid=int(z["native_grid"]),
+                                num_iterations=iters, num_cameras=cams)
+    return synth_state_dict(spec, seed=int(z["seed"]))
+
+
+def _exif(z, key):
+    return {k: torch.from_numpy(z[f"{key}:exif:{k}"])
+            for k in ("camera_idx", "focal_length", "aperture", "iso")}
+
+
+@pytest.mark.parametrize("size", [56, 70, 224])
+def test_full_model_forward(golden_dir, size):
+    z = load(golden_dir, "g7_full_model")
+    sd = _full_sd(z)
+    key = f"full:{size}"
+    x = torch.from_numpy(z[key + ":x"])
+    exif = _exif(z, key)
+    d, c, a = O.forward(sd, x, exif, return_attention=True)
+    close(d, z[key + ":depth"], rtol=1e-4)
+    close(c, z[key + ":conf"], rtol=1e-4)
+    close(a, z[key + ":attn"], rtol=1e-3, atol=1e-8)
+    # the goldens keep the confidence ReLU alive (conf != sigmoid(bias))
+    assert not np.allclose(z[key + ":conf"], z[key + ":conf"][0])
+    exif2 = {k: v.unsqueeze(1) for k, v in exif.items()}
+    d2, c2 = O.forward(sd, x, exif2)
+    close(d2, d, rtol=0, atol=0)
+    d3, c3 = O.forward(sd, x, None)
+    close(d3, z[key + ":depth_noexif"], rtol=1e-4)
+    close(c3, z[key + ":conf_noexif"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("size", [56, 70, 224])
+def test_full_model_guided(golden_dir, size):
+    z = load(golden_dir, "g7_full_model")
+    sd = _full_sd(z)
+    key = f"full:{size}"
+    x = torch.from_numpy(z[key + ":x"])
+    for name in O.INSTRUCTIONS:
+        _, _, ga = O.forward_with_guidance(sd, x, _exif(z, key), name)
+        close(ga, z[f"{key}:guided:{name}"], rtol=2e-3, atol=1e-9)
+    if size == 56:
+        proj = (torch.from_numpy(z[key + ":guided_proj_w"]), torch.from_numpy(z[key + ":guided_proj_b"]))
+        d, c, _ = O.forward_with_guidance(sd, x, _exif(z, key), "center", temp_projection=proj)
+        close(d, z[key + ":guided_depth"], rtol=1e-4)
+        close(c, z[key + ":guided_conf"], rtol=1e-4)
+
+
+def test_full_model_variants(golden_dir):
+    z = load(golden_dir, "g7_full_model")
+    x = torch.from_numpy(z["noexif:56:x"])
+    d, c, a = O.forward(_full_sd(z, cams=0), x, None, return_attention=True)
+    close(d, z["noexif:56:depth"], rtol=1e-4)
+    close(c, z["noexif:56:conf"], rtol=1e-4)
+    close(a, z["noexif:56:attn"], rtol=1e-3, atol=1e-8)
+    x = torch.from_numpy(z["it2:56:x"])
+    d, c, a = O.forward(_full_sd(z, iters=2), x, _exif(z, "it2:56"), return_attention=True,
+                        focus_strength=0.4)
+    close(d, z["it2:56:depth"], rtol=1e-4)
+    close(c, z["it2:56:conf"], rtol=1e-4)
+    close(a, z["it2:56:attn"], rtol=1e-3, atol=1e-8)
