@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Throughput of the Cognitive-Aim depth forward pass on MI355X.
+
+One step = one `model.forward(images, exif)` over a resident synthetic batch of
+32 images at 518x518 per GPU (BASELINE config 2: full_cognitive, B=32, 1 GPU;
+config 4 is the same per-GPU batch on 8 GPUs, image-sharded, with one RCCL
+all-gather of the per-image [depth, confidence] pairs per step).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODULES = ["ambient_stream", "iterative_focal_stream", "exif_prior_database"]
+PEAK_TFLOPS = 2500.0       # dense bf16/fp16 MFMA peak of one MI355X
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_per_image(size: int, iters: int, layers: int = 12, D: int = 768, patch: int = 14) -> float:
+    """De-duplicated dense formulation (2*MAC): backbone + I focal-stream calls."""
+    n = (size // patch) ** 2
+    t = n + 1
+    backbone = 2 * (3 * patch * patch * D * n + layers * (12 * D * D * t + 2 * D * t * t))
+    focal = iters * 2 * (3 * D * D * n + 2 * D * n * n)
+    return float(backbone + focal)
+
+
+def gemm_flops(name, args):
+    """FLOPs of one GEMM launch from its C-ABI arguments (None for non-GEMM calls)."""
+    if name in ("cogaim_gemm_bias_half", "cogaim_gemm_bias_gelu_half"):
+        M, N, K = args[4], args[5], args[6]
+    elif name == "cogaim_gemm_residual_f32":
+        M, N, K = args[5], args[6], args[7]
+    elif name == "cogaim_gemm_batched_f32":
+        M, N, K, batch = args[3], args[4], args[5], args[12]
+        return 2.0 * M * N * K * batch, (M, N, K, batch)
+    elif name == "cogaim_gemm_vt":
+        M, N, K = args[4] * args[5], args[6], args[7]
+    elif name == "cogaim_gemm_patch_embed":
+        M, N, K = args[5] * args[6], args[7], args[8]
+    elif name == "cogaim_mhsa_fwd":
+        B, T, H = args[3], args[4], args[5]
+        return 4.0 * B * H * T * T * 64, (B, T, H)
+    else:
+        return None, None
+    return 2.0 * M * N * K, (M, N, K)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=518)
+    ap.add_argument("--iters", type=int, default=3, help="focal refinement iterations")
+    ap.add_argument("--dtype", default=os.environ.get("COGAIM_DTYPE", "fp16"), choices=["fp16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from cognitive_aim_depth_estimation_amd import create_model, _lib
+    cfg = {"cognitive_modules": MODULES, "compute_dtype": args.dtype,
+           "focal_config": {"num_iterations": args.iters, "focus_strength": 1.5}, "init_seed": 0}
+    model = create_model(cfg, {"num_cameras": 71}, device=dev)
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randn(B, 3, args.size, args.size, device=dev, generator=g)
+    exif = {"camera_idx": torch.zeros(B, dtype=torch.long, device=dev),
+            "focal_length": torch.full((B,), 50.0, device=dev),
+            "aperture": torch.full((B,), 2.8, device=dev), "iso": torch.full((B,), 100.0, device=dev)}
+    gathered = torch.empty(world * B, 2, device=dev) if world > 1 else None
+
+    def step():
+        d, c = model(images, exif)
+        if world > 1:   # per-image scalars of every shard to every rank (RCCL over xGMI)
+            dist.all_gather_into_tensor(gathered, torch.cat([d, c], dim=1))
+        return d, c
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        d, c = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(d).all() and torch.isfinite(c).all()
+
+    ms_per_step = 1000.0 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+    fpi = flops_per_image(args.size, args.iters)
+    out = {
+        "metric": "images/sec @518x518 full_cognitive forward (depth+confidence)",
+        "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic (randn images, demo-default EXIF, seeded random-init weights)",
+        "config": {"workload": f"full_cognitive forward, B={B}/GPU, {args.size}x{args.size}, "
+                               f"ViT-B/14 12 layers + {args.iters} focal iterations",
+                   "global_batch": world * B, "sharding": f"image-sharded dp{world}" if world > 1 else "single GPU"},
+        "algorithmic_gflop_per_image": round(fpi / 1e9, 1),
+        "mfma_frac_end_to_end": round(value / world * fpi / 1e12 / PEAK_TFLOPS, 4),
+    }
+
+    if rank == 0 and not args.no_kernel_profile:
+        # per-kernel durations: HIP events on the launch stream around every C-ABI launch of 3 more steps
+        _lib.PROFILE = []
+        for _ in range(3):
+            model(images, exif)
+        torch.cuda.synchronize()
+        prof, _lib.PROFILE = _lib.PROFILE, None
+        groups = {}
+        for name, a, e0, e1 in prof:
+            fl, shape = gemm_flops(name, a)
+            key = (name, shape)
+            gsum = groups.setdefault(key, [0.0, 0, fl])
+            gsum[0] += e0.elapsed_time(e1)
+            gsum[1] += 1
+        total_ms = sum(v[0] for v in groups.values()) / 3
+        top = sorted(groups.items(), key=lambda kv: -kv[1][0])
+        out["kernel_breakdown_ms_per_step"] = {f"{k[0]}{list(k[1]) if k[1] else ''}": round(v[0] / 3, 3) for k, v in top[:12]}
+        out["kernel_sum_ms_per_step"] = round(total_ms, 3)
+        (dname, dshape), (dms, dcnt, dfl) = next((kv for kv in top if kv[1][2]), top[0])
+        avg_ms = dms / dcnt
+        achieved = dfl / (avg_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": f"{dname}{list(dshape)}", "avg_launch_ms": round(avg_ms, 4),
+                           "achieved": round(achieved, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cogaim_oracle as O
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        nb = 2
+        xc = images[:nb].cpu()
+        ec = {k: v[:nb].cpu() for k, v in exif.items()}
+        with torch.no_grad():
+            O.forward(sd, xc[:1], {k: v[:1] for k, v in ec.items()})      # warm-up
+            t1 = time.perf_counter()
+            d_ref, c_ref = O.forward(sd, xc, ec)
+            t_dedup = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            O.forward_faithful_schedule(sd, xc[:1], {k: v[:1] for k, v in ec.items()})
+            t_faithful = time.perf_counter() - t1
+        rel = float(((d[:nb].cpu() - d_ref).abs() / d_ref.abs()).max())
+        relc = float(((c[:nb].cpu() - c_ref).abs() / c_ref.abs()).max())
+        out["cpu_baseline"] = {
+            "value": round(nb / t_dedup, 3), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{nb} images of the same batch through oracle/cogaim_oracle.py (PyTorch CPU fp32, "
+                      f"de-duplicated schedule, {t_dedup:.1f} s)",
+            "faithful_schedule_img_s": round(1.0 / t_faithful, 3),
+            "faithful_schedule_note": "1 image through the reference's as-executed schedule "
+                                      "(2 backbone + 3 focal passes, Python position loop)",
+            "host_cpus": os.cpu_count()}
+        out["parity_vs_oracle"] = {"depth_max_rel_err": rel, "conf_max_rel_err": relc, "images": nb}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,8 +76,20 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# When set to a list, every launch is bracketed by events on the launch stream and
+# (name, args, start_event, end_event) is appended: per-kernel timing for bench.py.
+PROFILE = None
+
+
 def call(name: str, *args):
-    rc = getattr(lib(), name)(*args)
+    if PROFILE is not None and name not in _NO_STATUS:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib(), name)(*args)
+        e1.record()
+        PROFILE.append((name, args, e0, e1))
+    else:
+        rc = getattr(lib(), name)(*args)
     if name not in _NO_STATUS and rc != 0:
         raise CogaimError(f"{name} failed with code {rc}")
     return rc

@@ -201,8 +201,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmShape g, Epi epi) {
 }
 
 template <class T, class Epi, bool SWAP>
-int launch(const GemmShape& g, const Epi& epi, int batch, hipStream_t st) {
-  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (g.N & 3) != 0 ||
+int launch(const GemmShape& g, const Epi& epi, int batch, hipStream_t st, bool ragged_n = false) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (!ragged_n && (g.N & 3) != 0) ||
       (g.lda & 7) != 0 || (g.ldw & 7) != 0)
     return COGAIM_EINVAL;
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
@@ -252,10 +252,12 @@ int cogaim_gemm_batched_f32(const void* A, const void* W, float* out, int M, int
                             long long strideA, long long strideW, long long strideC, int batch, int dtype,
                             void* stream) {
   GemmShape g{A, W, M, N, K, lda, ldw, strideA, strideW};
-  if ((ldc & 3) || (strideC & 3) || (strideA & 7) || (strideW & 7) || batch <= 0) return COGAIM_EINVAL;
+  // N need not be a multiple of 4: the last 4-wide store of a row may spill into the row padding
+  if ((ldc & 3) || ldc < ((N + 3) & ~3) || (strideC & 3) || (strideA & 7) || (strideW & 7) || batch <= 0)
+    return COGAIM_EINVAL;
   EpiStoreF32 e{out, ldc, strideC, M, N};
-  return DISPATCH_T(dtype, (launch<__bf16, EpiStoreF32, true>(g, e, batch, (hipStream_t)stream)),
-                    (launch<_Float16, EpiStoreF32, true>(g, e, batch, (hipStream_t)stream)));
+  return DISPATCH_T(dtype, (launch<__bf16, EpiStoreF32, true>(g, e, batch, (hipStream_t)stream, true)),
+                    (launch<_Float16, EpiStoreF32, true>(g, e, batch, (hipStream_t)stream, true)));
 }
 
 // Patch-embedding GEMM: rows are im2col'ed patches (B*P rows, K padded to a multiple of 64);

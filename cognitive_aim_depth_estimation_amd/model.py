@@ -228,7 +228,7 @@ class CognitiveAimModel(nn.Module):
         self.layer_norm_eps = float(bb.get("layer_norm_eps", 1e-6))
         if self.feature_dim != 64 * self.num_heads:
             raise NotImplementedError("attention kernel is built for head_dim 64")
-        self.compute_dtype = str(config.get("compute_dtype", os.environ.get("COGAIM_DTYPE", "bf16")))
+        self.compute_dtype = str(config.get("compute_dtype", os.environ.get("COGAIM_DTYPE", "fp16")))
         if self.compute_dtype not in _DTYPES:
             raise ValueError(f"compute_dtype must be one of {sorted(_DTYPES)}")
 
