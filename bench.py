@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--size", type=int, default=518)
     ap.add_argument("--iters", type=int, default=3, help="focal refinement iterations")
     ap.add_argument("--dtype", default=os.environ.get("COGAIM_DTYPE", "fp16"), choices=["fp16", "bf16"])
+    ap.add_argument("--streams", type=int, default=1, help="split each batch over this many HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     args = ap.parse_args()
@@ -95,8 +96,25 @@ def main():
             "aperture": torch.full((B,), 2.8, device=dev), "iso": torch.full((B,), 100.0, device=dev)}
     gathered = torch.empty(world * B, 2, device=dev) if world > 1 else None
 
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+    chunks = torch.arange(B).chunk(args.streams) if streams else None
+
+    def forward_batch():
+        if not streams:
+            return model(images, exif)
+        cur = torch.cuda.current_stream()
+        outs = []
+        for s_, idx in zip(streams, chunks):
+            s_.wait_stream(cur)
+            with torch.cuda.stream(s_):
+                lo, hi = int(idx[0]), int(idx[-1]) + 1
+                outs.append(model(images[lo:hi], {k: v[lo:hi] for k, v in exif.items()}))
+        for s_ in streams:
+            cur.wait_stream(s_)
+        return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+
     def step():
-        d, c = model(images, exif)
+        d, c = forward_batch()
         if world > 1:   # per-image scalars of every shard to every rank (RCCL over xGMI)
             dist.all_gather_into_tensor(gathered, torch.cat([d, c], dim=1))
         return d, c
@@ -113,6 +131,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    model.synchronize()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -35,14 +35,15 @@ SIGNATURES = {
     "cogaim_focal_var_flag": [P, I, I, P, I, P],
     "cogaim_focal_weighted_colsum": [P, I, LL, P, P, P, P, I, I, P],
     "cogaim_focal_reduce_u": [P, P, P, I, I, P],
-    "cogaim_weighted_tokens": [P, LL, P, P, P, P, I, I, I, P],
+    "cogaim_weighted_tokens_rows": [],
+    "cogaim_weighted_tokens": [P, LL, P, P, P, P, P, I, I, I, P],
     "cogaim_guided_attention": [P, P, P, I, I, F, F, P],
     "cogaim_linear_f32": [P, I, P, P, P, P, I, I, I, I, I, P],
-    "cogaim_exif_prep": [P, P, P, P, P, I, P, I, P, I, P],
+    "cogaim_exif_prep": [P, P, P, P, P, I, I, P, I, P, I, P, P],
     "cogaim_heads": [P, I, P, P, P, P, P, P, P, P, I, P],
 }
 
-_NO_STATUS = {"cogaim_version", "cogaim_focal_colsum_rows"}
+_NO_STATUS = {"cogaim_version", "cogaim_focal_colsum_rows", "cogaim_weighted_tokens_rows"}
 _lib = None
 
 

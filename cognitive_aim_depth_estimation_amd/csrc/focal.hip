@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void focal_prep_kernel(const float* __restrict
   }
 }
 
-constexpr int CS_ROWS = 32;   // score rows per block
+constexpr int CS_ROWS = 64;   // score rows per block
 
 // part[b][blk][c] = sum over the block's rows n of w_n * exp2(S[n][c] - m_n) * inv_n
 // STATS: m_n, inv_n are computed here (and stored); w_n = 1.   else: read m, inv; w_n = roww[b][n].
@@ -51,12 +51,22 @@ __global__ __launch_bounds__(256) void focal_colsum_kernel(const float* __restri
     for (int rr = wave; rr < CS_ROWS; rr += 4) {
       const int row = r0 + rr;
       if (row < N) {
-        const float* sr = Sb + (size_t)row * ldS;
+        const float* sr = Sb + (size_t)row * ldS;   // rows are 16-B aligned (ldS % 4 == 0)
+        const int n4 = N & ~3;
         float mx = -INFINITY;
-        for (int c = lane; c < N; c += 64) mx = fmaxf(mx, sr[c]);
+        for (int c = lane * 4; c < n4; c += 256) {
+          const float4 v = *reinterpret_cast<const float4*>(sr + c);
+          mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+        }
+        for (int c = n4 + lane; c < N; c += 64) mx = fmaxf(mx, sr[c]);
         mx = wave_max(mx);
         float sum = 0.f;
-        for (int c = lane; c < N; c += 64) sum += __builtin_amdgcn_exp2f(sr[c] - mx);
+        for (int c = lane * 4; c < n4; c += 256) {
+          const float4 v = *reinterpret_cast<const float4*>(sr + c);
+          sum += (__builtin_amdgcn_exp2f(v.x - mx) + __builtin_amdgcn_exp2f(v.y - mx)) +
+                 (__builtin_amdgcn_exp2f(v.z - mx) + __builtin_amdgcn_exp2f(v.w - mx));
+        }
+        for (int c = n4 + lane; c < N; c += 64) sum += __builtin_amdgcn_exp2f(sr[c] - mx);
         sum = wave_sum(sum);
         if (lane == 0) {
           m_s[rr] = mx; i_s[rr] = 1.0f / sum;
@@ -82,10 +92,23 @@ __global__ __launch_bounds__(256) void focal_colsum_kernel(const float* __restri
   }
 }
 
+// colsum[b][c] = sum_blk part[b][blk][c]      (wide grid: one thread per column)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nblk,
+                                                              float* __restrict__ out, int N) {
+  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  const float* p = part + (size_t)b * nblk * N + c;
+  float s0 = 0.f, s1 = 0.f;
+  int k = 0;
+  for (; k + 1 < nblk; k += 2) { s0 += p[(size_t)k * N]; s1 += p[(size_t)(k + 1) * N]; }
+  if (k < nblk) s0 += p[(size_t)k * N];
+  out[(size_t)b * N + c] = s0 + s1;
+}
+
 // per image: a = renorm(clamp(renorm(colmean + centre_bias)));  model.py:234-282
-__global__ __launch_bounds__(256) void focal_attention_vector_kernel(const float* __restrict__ part, int nblk,
+__global__ __launch_bounds__(256) void focal_attention_vector_kernel(const float* colsum,
                                                                      const float* __restrict__ cbias,
-                                                                     float* __restrict__ a, double* __restrict__ stats,
+                                                                     float* a, double* __restrict__ stats,
                                                                      const float* __restrict__ scale_in,
                                                                      float* __restrict__ scale_out, float focus_strength,
                                                                      int N) {
@@ -96,9 +119,7 @@ __global__ __launch_bounds__(256) void focal_attention_vector_kernel(const float
   float s1 = 0.f; double d1 = 0.0, d2 = 0.0;
   const float invN = 1.0f / (float)N;
   for (int c = tid; c < N; c += 256) {
-    float cs = 0.f;
-    for (int k = 0; k < nblk; ++k) cs += part[((size_t)b * nblk + k) * N + c];
-    const float pa = cs * invN + cbias[c];
+    const float pa = colsum[(size_t)b * N + c] * invN + cbias[c];
     ab[c] = pa; s1 += pa; d1 += pa; d2 += (double)pa * pa;
   }
   const float t1 = block_sum_256(s1, red);
@@ -133,44 +154,41 @@ __global__ void focal_var_flag_kernel(const double* __restrict__ stats, int B, i
   flags[slot] = (var < 1e-6) ? 1 : 0;
 }
 
-// u[b][c] = sum_blk part[b][blk][c];  usum[b] = sum_c u[b][c]
-__global__ __launch_bounds__(256) void focal_reduce_u_kernel(const float* __restrict__ part, int nblk,
-                                                             float* __restrict__ u, float* __restrict__ usum, int N) {
+// usum[b] = sum_c u[b][c]
+__global__ __launch_bounds__(256) void row_sum_kernel(const float* __restrict__ u, float* __restrict__ usum, int N) {
   __shared__ float red[4];
   const int b = blockIdx.x, tid = threadIdx.x;
   float s = 0.f;
-  for (int c = tid; c < N; c += 256) {
-    float cs = 0.f;
-    for (int k = 0; k < nblk; ++k) cs += part[((size_t)b * nblk + k) * N + c];
-    u[(size_t)b * N + c] = cs; s += cs;
-  }
+  for (int c = tid; c < N; c += 256) s += u[(size_t)b * N + c];
   const float t = block_sum_256(s, red);
   if (tid == 0) usum[b] = t;
 }
 
-// out[b][d] = sum_n w[b][n] * (tok[b][n][d] * scale[b][n] + pe[n][d])     (scale, pe optional)
-__global__ __launch_bounds__(256) void focal_weighted_tokens_kernel(const float* __restrict__ tok,
-                                                                    long long tok_stride_b,
-                                                                    const float* __restrict__ scale,
-                                                                    const float* __restrict__ pe,
-                                                                    const float* __restrict__ w, float* __restrict__ out,
-                                                                    int N, int D) {
-  __shared__ float red[4][64];
-  const int b = blockIdx.y, tid = threadIdx.x;
-  const int col = blockIdx.x * 64 + (tid & 63), rg = tid >> 6;
-  float acc = 0.f;
-  if (col < D) {
-    const float* tb = tok + b * tok_stride_b;
-    for (int n = rg; n < N; n += 4) {
-      float x = tb[(size_t)n * D + col];
-      if (scale) x *= scale[(size_t)b * N + n];
-      if (pe) x += pe[(size_t)n * D + col];
-      acc += w[(size_t)b * N + n] * x;
+// part[b][chunk][d] = sum_{n in chunk} w[b][n] * (tok[b][n][d] * scale[b][n] + pe[n][d])   (scale, pe optional)
+constexpr int WT_ROWS = 32;
+__global__ __launch_bounds__(256) void weighted_tokens_partial_kernel(const float* __restrict__ tok,
+                                                                      long long tok_stride_b,
+                                                                      const float* __restrict__ scale,
+                                                                      const float* __restrict__ pe,
+                                                                      const float* __restrict__ w,
+                                                                      float* __restrict__ part, int nchunk, int N, int D) {
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int n0 = chunk * WT_ROWS, n1 = min(N, n0 + WT_ROWS);
+  const float* tb = tok + b * tok_stride_b;
+  for (int c = threadIdx.x * 4; c < D; c += 1024) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = n0; n < n1; ++n) {
+      float4 x = *reinterpret_cast<const float4*>(tb + (size_t)n * D + c);
+      const float wn = w[(size_t)b * N + n];
+      if (scale) { const float s = scale[(size_t)b * N + n]; x.x *= s; x.y *= s; x.z *= s; x.w *= s; }
+      if (pe) {
+        const float4 p = *reinterpret_cast<const float4*>(pe + (size_t)n * D + c);
+        x.x += p.x; x.y += p.y; x.z += p.z; x.w += p.w;
+      }
+      acc.x += wn * x.x; acc.y += wn * x.y; acc.z += wn * x.z; acc.w += wn * x.w;
     }
+    *reinterpret_cast<float4*>(part + ((size_t)b * nchunk + chunk) * D + c) = acc;
   }
-  red[rg][tid & 63] = acc;
-  __syncthreads();
-  if (rg == 0 && col < D) out[(size_t)b * D + col] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
 // guided[b][c] = softmax_c((0.7 mask[c] + 0.3 a[b][c]) / 0.05)     (model.py:1401-1409)
@@ -243,8 +261,10 @@ int cogaim_focal_attention_vector(const float* part, const float* center_bias, f
                                   void* stream) {
   if (B <= 0 || N <= 0) return COGAIM_EINVAL;
   const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
-  hipLaunchKernelGGL(focal_attention_vector_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, part, nblk, center_bias,
-                     a, stats, scale_in, scale_out, focus_strength, N);
+  // the reduced column sums are staged in `a` itself (the kernel reads a[b][c] before overwriting it)
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, part, nblk, a, N);
+  hipLaunchKernelGGL(focal_attention_vector_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)a,
+                     center_bias, a, stats, scale_in, scale_out, focus_strength, N);
   return COGAIM_LAUNCH_CHECK();
 }
 
@@ -257,15 +277,22 @@ int cogaim_focal_var_flag(const double* stats, int B, int N, int* flags, int slo
 int cogaim_focal_reduce_u(const float* part, float* u, float* usum, int B, int N, void* stream) {
   if (B <= 0 || N <= 0) return COGAIM_EINVAL;
   const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
-  hipLaunchKernelGGL(focal_reduce_u_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, part, nblk, u, usum, N);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, part, nblk, u, N);
+  hipLaunchKernelGGL(row_sum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)u, usum, N);
   return COGAIM_LAUNCH_CHECK();
 }
 
+int cogaim_weighted_tokens_rows() { return WT_ROWS; }
+
+// workspace: fp32 [B * ceil(N / cogaim_weighted_tokens_rows()) * D]
 int cogaim_weighted_tokens(const float* tok, long long tok_stride_b, const float* scale, const float* pe, const float* w,
-                           float* out, int B, int N, int D, void* stream) {
-  if (B <= 0 || N <= 0 || D <= 0) return COGAIM_EINVAL;
-  hipLaunchKernelGGL(focal_weighted_tokens_kernel, dim3((D + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, tok,
-                     tok_stride_b, scale, pe, w, out, N, D);
+                           float* out, float* workspace, int B, int N, int D, void* stream) {
+  if (B <= 0 || N <= 0 || D <= 0 || (D & 3) || (tok_stride_b & 3)) return COGAIM_EINVAL;
+  const int nchunk = (N + WT_ROWS - 1) / WT_ROWS;
+  hipLaunchKernelGGL(weighted_tokens_partial_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, tok,
+                     tok_stride_b, scale, pe, w, workspace, nchunk, N, D);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 255) / 256, B), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, nchunk, out, D);
   return COGAIM_LAUNCH_CHECK();
 }
 

@@ -38,8 +38,19 @@ template <class T> struct EpiBiasHalf {           // out16 = (acc + bias) [* sca
   }
 };
 
-__device__ __forceinline__ float gelu_erf(float x) {  // exact GELU (hidden_act="gelu")
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+// Exact-erf GELU (hidden_act="gelu"): x * Phi(x) with Phi from the Abramowitz-Stegun 7.1.26
+// rational form of erfc (|abs error| <= 1.5e-7, far below the 16-bit rounding of the output);
+// the negative branch uses erfc directly, so there is no cancellation in the tail.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const float erfc_half = 0.5f * p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  return x * (x < 0.f ? erfc_half : 1.0f - erfc_half);
 }
 
 template <class T> struct EpiBiasGeluHalf {

@@ -38,13 +38,19 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
 }
 
 // feat[b][0:E] = emb[idx[b]][0:E];  cont[b] = {focal_length, aperture, log(iso + 1)}
+// An index outside [0, num_emb) raises *err (when given) and reads row 0 instead of faulting.
 __global__ void exif_prep_kernel(const long long* __restrict__ idx, const float* __restrict__ fl,
                                  const float* __restrict__ ap, const float* __restrict__ iso,
-                                 const float* __restrict__ emb, int E, float* __restrict__ feat, int ldf,
-                                 float* __restrict__ cont, int B) {
+                                 const float* __restrict__ emb, int num_emb, int E, float* __restrict__ feat, int ldf,
+                                 float* __restrict__ cont, int B, int* __restrict__ err) {
   const int b = blockIdx.x, t = threadIdx.x;
   if (b >= B) return;
-  for (int e = t; e < E; e += blockDim.x) feat[(size_t)b * ldf + e] = emb[(size_t)idx[b] * E + e];
+  long long row = idx[b];
+  if (row < 0 || row >= num_emb) {
+    if (t == 0 && err) *err = 1;
+    row = 0;
+  }
+  for (int e = t; e < E; e += blockDim.x) feat[(size_t)b * ldf + e] = emb[(size_t)row * E + e];
   if (t == 0) { cont[b * 3] = fl[b]; cont[b * 3 + 1] = ap[b]; cont[b * 3 + 2] = logf(iso[b] + 1.0f); }
 }
 
@@ -86,10 +92,11 @@ int cogaim_linear_f32(const float* x, int ldx, const float* W, const float* bias
 }
 
 int cogaim_exif_prep(const long long* camera_idx, const float* focal_length, const float* aperture, const float* iso,
-                     const float* embedding, int emb_dim, float* feat, int ldf, float* cont, int B, void* stream) {
-  if (B <= 0 || emb_dim <= 0 || ldf < emb_dim) return COGAIM_EINVAL;
+                     const float* embedding, int num_embeddings, int emb_dim, float* feat, int ldf, float* cont, int B,
+                     int* err_flag, void* stream) {
+  if (B <= 0 || emb_dim <= 0 || num_embeddings <= 0 || ldf < emb_dim) return COGAIM_EINVAL;
   hipLaunchKernelGGL(exif_prep_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, camera_idx, focal_length, aperture,
-                     iso, embedding, emb_dim, feat, ldf, cont, B);
+                     iso, embedding, num_embeddings, emb_dim, feat, ldf, cont, B, err_flag);
   return COGAIM_LAUNCH_CHECK();
 }
 

@@ -335,11 +335,13 @@ class CognitiveAimModel(nn.Module):
         return t
 
     def _workspace(self, B: int, gh: int, gw: int) -> dict:
-        key = (B, gh, gw, self.compute_dtype)
+        # one workspace per (shape, stream): calls queued on different streams may overlap
+        key = (B, gh, gw, self.compute_dtype, stream_ptr())
         ws = self._ws.get(key)
         if ws is not None:
             return ws
         if len(self._ws) > 4:
+            self.synchronize()
             self._ws.clear()
         dev = self._packed["device"]
         _, tdt = _DTYPES[self.compute_dtype]
@@ -363,8 +365,11 @@ class CognitiveAimModel(nn.Module):
             "part": torch.empty(B * nblk * N, **f32), "attn": torch.empty(B, N, **f32),
             "scale": torch.empty(2, B, N, **f32), "stats": torch.empty(B, 2, device=dev, dtype=torch.float64),
             "flags": torch.zeros(16, device=dev, dtype=torch.int32),
+            "flags_host": torch.zeros(16, dtype=torch.int32).pin_memory(), "flags_event": torch.cuda.Event(),
             "u": torch.empty(B, N, **f32), "usum": torch.empty(B, **f32),
             "wt": torch.empty(B, D, **f32), "w": torch.empty(B, D, **f32),
+            "wtpart": torch.empty(B * ((N + call("cogaim_weighted_tokens_rows") - 1)
+                                       // call("cogaim_weighted_tokens_rows")) * D, **f32),
             "t256": torch.empty(B, 256, **f32), "t128": torch.empty(B, 128, **f32), "t64": torch.empty(B, 64, **f32),
             "feats": torch.empty(B, 64 * max(1, self.num_iterations), **f32),
             "exf": torch.empty(B, 128, **f32), "cont": torch.empty(B, 3, **f32),
@@ -435,7 +440,7 @@ class CognitiveAimModel(nn.Module):
             call("cogaim_focal_var_flag", ptr(ws["stats"]), B, N, ptr(ws["flags"]), i % 16, st)
             call("cogaim_focal_weighted_colsum", S, ldS, N * ldS, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["attn"]), ptr(ws["part"]), B, N, st)
             call("cogaim_focal_reduce_u", ptr(ws["part"]), ptr(ws["u"]), ptr(ws["usum"]), B, N, st)
-            call("cogaim_weighted_tokens", tok, tstride, s_in, ptr(pe), ptr(ws["u"]), ptr(ws["wt"]), B, N, D, st)
+            call("cogaim_weighted_tokens", tok, tstride, s_in, ptr(pe), ptr(ws["u"]), ptr(ws["wt"]), ptr(ws["wtpart"]), B, N, D, st)
             self._linear(ptr(ws["wt"]), D, pfx + "value_proj", ptr(ws["w"]), D, B, bias_scale=ws["usum"])
             self._linear(ptr(ws["w"]), D, pfx + "projection.0", ptr(ws["t256"]), 256, B, act=1)
             self._linear(ptr(ws["t256"]), 256, pfx + "projection.3", ws["feats"].data_ptr() + 64 * i * 4, 64 * I, B)
@@ -448,12 +453,35 @@ class CognitiveAimModel(nn.Module):
     def _check_fallback_flags(self, ws):
         """The reference switches to other attention summaries when the whole-batch variance
         of (column mean + centre bias) is below 1e-6 (src/model.py:242-257).  The predicate is
-        evaluated on device; it is impossible for any grid larger than 1x1 (the centre bias
-        alone has variance far above the threshold), so a set flag is reported, not emulated."""
-        if self.num_iterations and bool(ws["flags"][: self.num_iterations].any().item()):
-            if ws["N"] > 1:
-                raise RuntimeError("focal attention variance fell below 1e-6: the reference's degenerate-"
-                                   "attention fallbacks (src/model.py:242-257) are not built")
+        evaluated on device; it cannot fire for any grid larger than 1x1 (the centre bias alone
+        has variance far above the threshold), so a set flag is reported, not emulated.
+
+        The flags are copied to pinned host memory asynchronously and examined at the next
+        call on this workspace or in ``synchronize()``: no host stall inside the forward."""
+        self._examine_flags(ws)
+        ws["flags_host"].copy_(ws["flags"], non_blocking=True)
+        ws["flags_event"].record()
+        ws["flags_pending"] = True
+
+    def _examine_flags(self, ws, wait=True):
+        if ws.get("flags_pending"):
+            if wait:
+                ws["flags_event"].synchronize()
+            elif not ws["flags_event"].query():
+                return
+            ws["flags_pending"] = False
+            if int(ws["flags_host"][15]):
+                ws["flags"][15] = 0
+                raise IndexError("camera_idx out of range in an earlier forward (index out of range in self)")
+            if ws["N"] > 1 and bool(ws["flags_host"][: self.num_iterations].any()):
+                raise RuntimeError("focal attention variance fell below 1e-6 in an earlier forward: the "
+                                   "reference's degenerate-attention fallbacks (src/model.py:242-257) are not built")
+
+    def synchronize(self):
+        """Waits for all queued work of this model and raises any deferred device-side condition."""
+        torch.cuda.synchronize()
+        for ws in self._ws.values():
+            self._examine_flags(ws)
 
     def _ambient(self, ws, B, col):
         T, D = ws["T"], self.feature_dim
@@ -475,16 +503,14 @@ class CognitiveAimModel(nn.Module):
                 raise ValueError(f"exif_data['{k}'] has {t.numel()} entries for a batch of {B}")
             return t
         idx = vec("camera_idx", torch.int64)
-        n_cam = self._packed["f32"]["exif_prior.camera_embedding.weight"].shape[0]
-        if int(idx.min()) < 0 or int(idx.max()) >= n_cam:
-            raise IndexError("index out of range in self")
         return idx, vec("focal_length", torch.float32), vec("aperture", torch.float32), vec("iso", torch.float32)
 
     def _exif(self, exif_in, ws, B, col):
         idx, fl, ap, iso = exif_in
         emb = self._packed["f32"]["exif_prior.camera_embedding.weight"]
-        call("cogaim_exif_prep", ptr(idx), ptr(fl), ptr(ap), ptr(iso), ptr(emb), 64, ptr(ws["exf"]), 128,
-             ptr(ws["cont"]), B, stream_ptr())
+        # an out-of-range camera index is reported through flag slot 15 (examined with the other flags)
+        call("cogaim_exif_prep", ptr(idx), ptr(fl), ptr(ap), ptr(iso), ptr(emb), emb.shape[0], 64, ptr(ws["exf"]), 128,
+             ptr(ws["cont"]), B, ws["flags"].data_ptr() + 15 * 4, stream_ptr())
         self._linear(ptr(ws["cont"]), 3, "exif_prior.exif_encoder.0", ptr(ws["t64"]), 64, B, act=1)
         self._linear(ptr(ws["t64"]), 64, "exif_prior.exif_encoder.2", ws["exf"].data_ptr() + 64 * 4, 128, B)
         self._linear(ptr(ws["exf"]), 128, "exif_prior.fusion.0", ptr(ws["t256"]), 256, B, act=1)
@@ -605,7 +631,7 @@ class CognitiveAimModel(nn.Module):
             st = stream_ptr()
             call("cogaim_guided_attention", ptr(ws["attn"]), ptr(gdev), ptr(ws["guided"]), B, N, 0.7, 0.05, st)
             call("cogaim_weighted_tokens", ws["tokens"].data_ptr() + D * 4, T * D, None, None, ptr(ws["guided"]),
-                 ptr(ws["wt"]), B, N, D, st)
+                 ptr(ws["wt"]), ptr(ws["wtpart"]), B, N, D, st)
             self._linear(ptr(ws["wt"]), D, None, ws["cat"].data_ptr() + col * 4, 192, B, W=pw, bias=pb)
 
         ncols = self._features(images, exif_data, ws, B, focal_override=guided_focal)

@@ -108,9 +108,11 @@ int cogaim_focal_weighted_colsum(const float* S, int ldS, long long strideS, con
 int cogaim_focal_reduce_u(const float* part, float* u, float* usum, int B, int N, void* stream);
 
 /* out[b][:] = sum_n w[b][n] * (tok[b][n][:] * scale[b][n] + pe[n][:]);  scale/pe NULL = 1/0.
- * Used for (a^T P) Xt above and for the guided token sum of src/model.py:1412-1414. */
+ * Used for (a^T P) Xt above and for the guided token sum of src/model.py:1412-1414.
+ * workspace: fp32 [B * ceil(N / cogaim_weighted_tokens_rows()) * D]. */
+int cogaim_weighted_tokens_rows(void);
 int cogaim_weighted_tokens(const float* tok, long long tok_stride_b, const float* scale, const float* pe, const float* w,
-                           float* out, int B, int N, int D, void* stream);
+                           float* out, float* workspace, int B, int N, int D, void* stream);
 
 /* src/model.py:1401-1409: out = softmax((alpha*mask + (1-alpha)*a) / temperature). */
 int cogaim_guided_attention(const float* a, const float* mask, float* out, int B, int N, float alpha, float temperature,
@@ -124,9 +126,11 @@ int cogaim_guided_attention(const float* a, const float* mask, float* out, int B
 int cogaim_linear_f32(const float* x, int ldx, const float* W, const float* bias, const float* bias_scale, float* out,
                       int ldo, int B, int O, int K, int act, void* stream);
 
-/* src/model.py:491-514: camera embedding gather and [focal_length, aperture, log(iso+1)]. */
+/* src/model.py:491-514: camera embedding gather and [focal_length, aperture, log(iso+1)].
+ * A camera_idx outside [0, num_embeddings) sets *err_flag = 1 (if not NULL) and gathers row 0. */
 int cogaim_exif_prep(const long long* camera_idx, const float* focal_length, const float* aperture, const float* iso,
-                     const float* embedding, int emb_dim, float* feat, int ldf, float* cont, int B, void* stream);
+                     const float* embedding, int num_embeddings, int emb_dim, float* feat, int ldf, float* cont, int B,
+                     int* err_flag, void* stream);
 
 /* src/model.py:925-941,1120-1123: depth = Softplus(Linear), conf = Sigmoid(Linear(1,1)(ReLU(Linear))). */
 int cogaim_heads(const float* fused, int K, const float* wd, const float* bd, const float* wc, const float* bc,

@@ -185,8 +185,12 @@ def test_small_kernels():
     fl, ap, iso = rnd(B).abs() * 50, rnd(B).abs() * 4, rnd(B).abs() * 800
     emb = rnd(71, 64)
     feat, cont = torch.zeros(B, 128, device="cuda"), torch.zeros(B, 3, device="cuda")
-    call("cogaim_exif_prep", ptr(idx), ptr(fl), ptr(ap), ptr(iso), ptr(emb), 64, ptr(feat), 128, ptr(cont), B, stream_ptr())
-    assert torch.equal(feat[:, :64], emb[idx])
+    err = torch.zeros(1, device="cuda", dtype=torch.int32)
+    call("cogaim_exif_prep", ptr(idx), ptr(fl), ptr(ap), ptr(iso), ptr(emb), 71, 64, ptr(feat), 128, ptr(cont), B, ptr(err), stream_ptr())
+    assert torch.equal(feat[:, :64], emb[idx]) and int(err) == 0
+    bad = torch.tensor([0, 71, 3, -1, 12], device="cuda")
+    call("cogaim_exif_prep", ptr(bad), ptr(fl), ptr(ap), ptr(iso), ptr(emb), 71, 64, ptr(feat), 128, ptr(cont), B, ptr(err), stream_ptr())
+    assert int(err) == 1 and torch.equal(feat[1, :64], emb[0])
     assert torch.allclose(cont, torch.stack([fl, ap, torch.log(iso + 1)], 1), rtol=1e-6)
 
 
