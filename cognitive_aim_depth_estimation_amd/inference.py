@@ -1,0 +1,409 @@
+"""Inference harness: the reference ``demo.py`` surface with a real batch loop.
+
+Mirrors ``CognitiveAimInference`` of reference demo.py:26-600 (constructor,
+``predict``, ``predict_batch``, tolerant checkpoint loading, EXIF handling,
+preprocessing, heat-map rendering).  What changes is the loop of
+demo.py:406-432, which runs one image at a time: here images are preprocessed,
+stacked into batches, optionally sharded by image over the ranks of an
+initialised ``torch.distributed`` group (one process per GPU) and the per-image
+``[depth, confidence]`` pairs are all-gathered (RCCL on GPUs, gloo in tests).
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .model import create_model
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+DEFAULT_MODULES = ["ambient_stream", "iterative_focal_stream", "exif_prior_database"]
+DEFAULT_EXIF = {"FocalLength": 50.0, "FNumber": 2.8, "ISOSpeedRatings": 100}
+
+
+# --------------------------------------------------------------------------
+# host-side pieces (no GPU needed)
+# --------------------------------------------------------------------------
+def load_config(config_path: str) -> dict:
+    """YAML -> dict, with the two fix-ups of reference demo.py:39-53."""
+    import yaml
+    with open(config_path, "r", encoding="utf-8") as f:
+        config = yaml.safe_load(f)
+    config["debug_init"] = True
+    if "cognitive_modules" not in config:
+        config["cognitive_modules"] = list(DEFAULT_MODULES)
+    return config
+
+
+def camera_info_from_config(config: dict) -> Optional[dict]:
+    """reference demo.py:56-65: 71 cameras unless (model.)exif_config.num_cameras says otherwise."""
+    if "exif_prior_database" not in config.get("cognitive_modules", []):
+        return None
+    n = 71
+    if "exif_config" in config:
+        n = config["exif_config"].get("num_cameras", 71)
+    elif "model" in config and "exif_config" in (config["model"] or {}):
+        n = config["model"]["exif_config"].get("num_cameras", 71)
+    return {"num_cameras": n}
+
+
+def image_size_from_config(config: dict) -> Tuple[int, int]:
+    """reference demo.py:154-160."""
+    size = config["dataset"]["image_size"]
+    if isinstance(size, int):
+        return (size, size)
+    if isinstance(size, list) and len(size) == 1:
+        return (size[0], size[0])
+    return tuple(size)
+
+
+def preprocess_image(image, size: Tuple[int, int]) -> torch.Tensor:
+    """Resize -> ToTensor -> Normalize of reference demo.py:162-166 without torchvision:
+    PIL bilinear resize (what torchvision's Resize does for PIL input, antialias included),
+    HWC uint8 -> CHW float / 255, ImageNet mean/std.  ``size`` is (height, width)."""
+    from PIL import Image
+    img = image.convert("RGB").resize((size[1], size[0]), Image.BILINEAR)
+    arr = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).to(torch.float32) / 255.0
+    mean = torch.tensor(IMAGENET_MEAN).view(3, 1, 1)
+    std = torch.tensor(IMAGENET_STD).view(3, 1, 1)
+    return (arr - mean) / std
+
+
+def extract_exif(image_path: str) -> Optional[Dict]:
+    """reference demo.py:170-255: FocalLength / FNumber / ExposureTime / ISO with range checks, Make / Model."""
+    try:
+        from PIL import Image
+        from PIL.ExifTags import TAGS
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            image = Image.open(image_path)
+            try:
+                raw = image._getexif()
+            except Exception:
+                try:
+                    raw = dict(image.getexif().items()) or None
+                except Exception:
+                    raw = None
+            if raw is None:
+                return None
+
+            def val(v):
+                try:
+                    if isinstance(v, tuple) and len(v) == 2:
+                        return float(v[0]) / float(v[1])
+                    return float(v) if isinstance(v, (int, float)) else float(str(v))
+                except Exception:
+                    return None
+            out = {}
+            for tag_id, v in raw.items():
+                try:
+                    tag = TAGS.get(tag_id, tag_id)
+                    if tag == "FocalLength":
+                        x = val(v)
+                        if x and 10 <= x <= 500:
+                            out[tag] = x
+                    elif tag == "FNumber":
+                        x = val(v)
+                        if x and 1.0 <= x <= 32.0:
+                            out[tag] = x
+                    elif tag == "ExposureTime":
+                        x = val(v)
+                        if x and 0.0001 <= x <= 30.0:
+                            out[tag] = x
+                    elif tag == "ISOSpeedRatings":
+                        x = val(v)
+                        if x and 50 <= x <= 25600:
+                            out[tag] = int(x)
+                    elif tag in ("Make", "Model") and isinstance(v, str) and v.strip():
+                        out[tag] = v.strip()
+                except Exception:
+                    continue
+            return out or None
+    except Exception as e:
+        if "Corrupt EXIF" not in str(e):
+            print(f"EXIF extraction failed: {e}")
+        return None
+
+
+def exif_rows(exifs: Sequence[Optional[Dict]], camera_to_id: Dict[str, int]) -> Dict[str, torch.Tensor]:
+    """Batched form of reference demo.py:257-296 (defaults 50 mm, f/2.8, ISO 100, camera 0)."""
+    fl, ap, iso, cam = [], [], [], []
+    for e in exifs:
+        e = e or {}
+        fl.append(float(e.get("FocalLength", 50.0)))
+        ap.append(float(e.get("FNumber", 2.8)))
+        iso.append(float(e.get("ISOSpeedRatings", 100)))
+        cam.append(int(camera_to_id.get(e.get("Model", "unknown"), 0)))
+    return {"focal_length": torch.tensor(fl, dtype=torch.float32), "aperture": torch.tensor(ap, dtype=torch.float32),
+            "iso": torch.tensor(iso, dtype=torch.float32), "camera_idx": torch.tensor(cam, dtype=torch.long)}
+
+
+def heatmap_postprocess(attn: np.ndarray) -> np.ndarray:
+    """reference demo.py:533-552: cube, damp everything at or below the 70th percentile by 0.3,
+    min-max normalise, reshape to the (padded) square grid."""
+    a = np.power(np.asarray(attn, dtype=np.float64).ravel(), 3)
+    thr = np.percentile(a, 70)
+    a = np.where(a > thr, a, a * 0.3)
+    a = (a - a.min()) / (a.max() - a.min() + 1e-8)
+    n = len(a)
+    g = int(np.sqrt(n))
+    if g * g != n:
+        g = int(np.ceil(np.sqrt(n)))
+        a = np.concatenate([a, np.zeros(g * g - n)])
+    return a.reshape(g, g)
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous image shard of rank ``rank``: sizes differ by at most one."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_shards(local: torch.Tensor, n_total: int) -> torch.Tensor:
+    """All-gather of the per-image rows of every rank ([n_local, C] -> [n_total, C], shard order).
+    Shards are padded to a common length so that one collective suffices."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    per = (n_total + world - 1) // world
+    buf = torch.zeros(per, local.shape[1], device=local.device, dtype=local.dtype)
+    buf[: local.shape[0]] = local
+    out = torch.empty(world * per, local.shape[1], device=local.device, dtype=local.dtype)
+    dist.all_gather_into_tensor(out, buf)
+    rows = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        rows.append(out[r * per: r * per + (hi - lo)])
+    return torch.cat(rows, dim=0)
+
+
+# --------------------------------------------------------------------------
+# the harness
+# --------------------------------------------------------------------------
+class CognitiveAimInference:
+    def __init__(self, config_path: str, checkpoint_path: str, device: str = "auto", batch_size: int = 32,
+                 render: bool = True):
+        if device == "auto":
+            device = "cuda" if torch.cuda.is_available() else "cpu"
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("this build runs the forward pass only on an MI355X (ROCm) device; "
+                               "there is no CPU path (use the reference's own demo.py for CPU runs)")
+        print(f"Using device: {self.device}")
+        self.config = load_config(config_path)
+        camera_info = camera_info_from_config(self.config)
+        self.model = create_model(self.config, camera_info).to(self.device)
+        print(f"Model status: use_ambient={self.model.use_ambient}, use_focal={self.model.use_focal}, "
+              f"use_exif={self.model.use_exif}")
+        self._load_checkpoint(checkpoint_path)
+        self.model.eval()
+        self.image_size = image_size_from_config(self.config)
+        self.camera_to_id = {"unknown": 0}
+        self.batch_size = int(batch_size)
+        self.render = render
+
+    def _load_checkpoint(self, checkpoint_path: str):
+        """Tolerant loader of reference demo.py:89-150: accepts {'model_state_dict'|'main_model'|raw},
+        keeps entries whose name and shape match, and on ANY failure keeps the initial weights.
+        Unlike the reference it only unpickles tensors (weights_only=True)."""
+        print(f"Loading checkpoint: {checkpoint_path}")
+        try:
+            ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+            state = ckpt.get("model_state_dict") or ckpt.get("main_model") or ckpt
+            own = self.model.state_dict()
+            keep = {k: v for k, v in state.items() if k in own and own[k].shape == v.shape}
+            self.model.load_state_dict(keep, strict=False)
+            print(f"Successfully loaded {len(keep)}/{len(state)} parameters")
+        except Exception as e:
+            print(f"Error loading checkpoint: {e}")
+            print("Continuing with randomly initialized weights...")
+
+    # -- single image, same contract as reference demo.py:298-404 -----------------------------
+    def predict(self, image_path: str, instruction: Optional[str] = None) -> Tuple[float, float, Dict]:
+        res = self._run([image_path], [instruction])
+        return res[0]
+
+    # -- batch: same signature as reference demo.py:406-432, but batched and sharded ----------
+    def predict_batch(self, image_paths: list, instructions: Optional[list] = None) -> list:
+        if instructions is None:
+            instructions = [None] * len(image_paths)
+        elif len(instructions) != len(image_paths):
+            raise ValueError("Number of instructions must match number of images")
+        return self._run(list(image_paths), list(instructions), tolerate_errors=True)
+
+    def _run(self, paths: List[str], instructions: List[Optional[str]], tolerate_errors: bool = False) -> list:
+        import torch.distributed as dist
+        from PIL import Image
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        rank = dist.get_rank() if world > 1 else 0
+        n = len(paths)
+        lo, hi = shard_range(n, rank, world)
+        results: List[Optional[tuple]] = [None] * n
+        local = torch.full((hi - lo, 2), float("nan"))
+        loaded = []       # (global index, tensor, exif_raw, original size)
+        for i in range(lo, hi):
+            try:
+                image = Image.open(paths[i]).convert("RGB")
+                loaded.append((i, preprocess_image(image, self.image_size), extract_exif(paths[i]), image.size))
+            except Exception as e:
+                if not tolerate_errors:
+                    raise ValueError(f"Cannot load image {paths[i]}: {e}")
+                results[i] = (None, None, {"error": str(e)})
+        # group by instruction so that every forward is one homogeneous batch
+        groups: Dict[Optional[str], list] = {}
+        for item in loaded:
+            groups.setdefault(instructions[item[0]], []).append(item)
+        for instruction, items in groups.items():
+            for s in range(0, len(items), self.batch_size):
+                chunk = items[s: s + self.batch_size]
+                x = torch.stack([c[1] for c in chunk]).to(self.device, non_blocking=True)
+                exif = {k: v.to(self.device) for k, v in exif_rows([c[2] for c in chunk], self.camera_to_id).items()}
+                if hasattr(self.model, "_last_attention_weights"):
+                    delattr(self.model, "_last_attention_weights")          # reference demo.py:334-335
+                if instruction is not None:
+                    depth, conf = self.model.forward_with_guidance(x, exif, instruction)
+                else:
+                    depth, conf = self.model(x, exif)
+                attn = self.model.get_attention_weights()
+                dc = torch.cat([depth, conf], dim=1).float().cpu()
+                attn_cpu = attn.float().cpu().numpy() if attn is not None else None
+                for j, (i, xt, exif_raw, orig_size) in enumerate(chunk):
+                    local[i - lo] = dc[j]
+                    meta = {"image_path": paths[i], "original_size": orig_size,
+                            "processed_size": tuple(xt.shape[1:]), "exif_available": exif_raw is not None,
+                            "exif_source": "real" if exif_raw is not None else "default", "instruction": instruction,
+                            "cognitive_modules": self.config.get("cognitive_modules", []),
+                            "model_status": {"ambient": self.model.use_ambient, "focal": self.model.use_focal,
+                                             "exif": self.model.use_exif},
+                            "exif_data": exif_raw or dict(DEFAULT_EXIF, Model="Default", Make="Default")}
+                    results[i] = (float(dc[j, 0]), float(dc[j, 1]), meta)
+                    if self.render:
+                        self._save_prediction_image(paths[i], xt, float(dc[j, 0]), float(dc[j, 1]),
+                                                    None if attn_cpu is None else attn_cpu[j], instruction)
+        self.model.synchronize()
+        if world > 1:
+            everyone = gather_shards(local.to(self.device), n).cpu()
+            for i in range(n):
+                if results[i] is None and not torch.isnan(everyone[i, 0]):
+                    results[i] = (float(everyone[i, 0]), float(everyone[i, 1]),
+                                  {"image_path": paths[i], "instruction": instructions[i], "rank": "remote"})
+                elif results[i] is None:
+                    results[i] = (None, None, {"error": "failed on a remote rank"})
+        return results
+
+    def _save_prediction_image(self, image_path, image_tensor, depth_value, confidence_score, attention, instruction):
+        """Three-panel PNG of reference demo.py:471-600 (image | attention overlay | numbers)."""
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+            from scipy.ndimage import zoom
+        except Exception as e:            # rendering is optional plumbing, never the measured path
+            print(f"Prediction image skipped: {e}")
+            return
+        out_dir = Path("demo_results")
+        out_dir.mkdir(exist_ok=True)
+        stem = Path(image_path).stem
+        out_path = out_dir / (f"{stem}_{instruction}_prediction.png" if instruction else f"{stem}_prediction.png")
+        mean = torch.tensor(IMAGENET_MEAN).view(3, 1, 1)
+        std = torch.tensor(IMAGENET_STD).view(3, 1, 1)
+        img = torch.clamp(image_tensor.cpu() * std + mean, 0, 1).permute(1, 2, 0).numpy()
+        fig, axes = plt.subplots(1, 3, figsize=(18, 6))
+        axes[0].imshow(img)
+        axes[0].set_title("Original Image", fontsize=14, fontweight="bold")
+        axes[0].axis("off")
+        axes[1].imshow(img)
+        if attention is not None:
+            grid = heatmap_postprocess(attention)
+            h, w = img.shape[:2]
+            resized = zoom(grid, (h / grid.shape[0], w / grid.shape[1]), order=1)
+            im = axes[1].imshow(resized, cmap="plasma", alpha=0.6, interpolation="bilinear", vmin=0, vmax=1)
+            axes[1].set_title("Focus Map (Overlay)", fontsize=14, fontweight="bold")
+            cbar = plt.colorbar(im, ax=axes[1], fraction=0.046, pad=0.04)
+            cbar.set_label("Attention Weight", rotation=270, labelpad=15)
+        else:
+            axes[1].set_title("No Attention Data", fontsize=14)
+        axes[1].axis("off")
+        ax = axes[2]
+        ax.text(0.5, 0.7, f"Predicted Depth: {depth_value:.4f}m", ha="center", va="center", transform=ax.transAxes,
+                fontsize=16, fontweight="bold")
+        ax.text(0.5, 0.5, f"Confidence: {confidence_score:.4f}", ha="center", va="center", transform=ax.transAxes,
+                fontsize=14, color="blue")
+        if instruction:
+            ax.text(0.5, 0.3, f"Instruction: {instruction}", ha="center", va="center", transform=ax.transAxes,
+                    fontsize=12)
+        ax.set_title("Prediction Results")
+        ax.axis("off")
+        plt.tight_layout()
+        plt.savefig(out_path, dpi=150, bbox_inches="tight")
+        plt.close()
+        print(f"Prediction image saved to: {out_path}")
+
+
+def build_arg_parser():
+    """Flags of reference demo.py:604-611 plus --batch_size / --no_render."""
+    import argparse
+    p = argparse.ArgumentParser(description="Cognitive-Aim Experiment B Inference (MI355X build)")
+    p.add_argument("--config", type=str, default="configs/experiment_B.yaml", help="Configuration file path")
+    p.add_argument("--checkpoint", type=str, default="checkpoints/cognitive_aim_model.pth", help="Model checkpoint path")
+    p.add_argument("--image", type=str, help="Single image path")
+    p.add_argument("--image_dir", type=str, help="Image directory path")
+    p.add_argument("--instruction", type=str, help="Guidance instruction (center/left/right)")
+    p.add_argument("--output", type=str, default="inference_results.json", help="Output file path")
+    p.add_argument("--device", type=str, default="auto", help="Computing device (auto/cuda)")
+    p.add_argument("--batch_size", type=int, default=32, help="images per forward call")
+    p.add_argument("--no_render", action="store_true", help="skip the per-image PNG")
+    return p
+
+
+def list_images(image_dir: str) -> List[str]:
+    """reference demo.py:654-662."""
+    d = Path(image_dir)
+    paths = []
+    for ext in (".jpg", ".jpeg", ".png", ".bmp", ".tiff"):
+        paths.extend(d.glob(f"*{ext}"))
+        paths.extend(d.glob(f"*{ext.upper()}"))
+    return [str(p) for p in sorted(set(paths))]
+
+
+def main(argv=None):
+    args = build_arg_parser().parse_args(argv)
+    if not args.image and not args.image_dir:
+        raise ValueError("Must specify either --image or --image_dir")
+    if args.image and args.image_dir:
+        raise ValueError("Cannot specify both --image and --image_dir")
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:          # launched with torch.distributed.run: shard by image
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+        args.device = f"cuda:{os.environ.get('LOCAL_RANK', '0')}"
+    print("Initializing Cognitive-Aim inference engine...")
+    engine = CognitiveAimInference(args.config, args.checkpoint, args.device, args.batch_size, not args.no_render)
+    if args.image:
+        instruction = args.instruction if args.instruction else "center"        # reference demo.py:635
+        depth, conf, meta = engine.predict(args.image, instruction)
+        print("\n=== Inference Results ===")
+        print(f"Image: {args.image}\nDepth value: {depth:.4f}\nConfidence: {conf:.4f}")
+        print(f"Guidance instruction: {instruction}\nCognitive modules: {meta['cognitive_modules']}")
+        print(f"Model status: {meta['model_status']}")
+    else:
+        paths = list_images(args.image_dir)
+        if not paths:
+            raise ValueError(f"No image files found in directory {args.image_dir}")
+        print(f"Found {len(paths)} images")
+        results = engine.predict_batch(paths)
+        ok = [r for r in results if r[0] is not None]
+        print(f"\n=== Batch Inference Results ===\nTotal images: {len(paths)}\nSuccessfully processed: {len(ok)}"
+              f"\nFailed: {len(paths) - len(ok)}")
+        if ok:
+            depths = [r[0] for r in ok]
+            print(f"Depth range: {min(depths):.4f} - {max(depths):.4f}\nAverage depth: {np.mean(depths):.4f}"
+                  f"\nAverage confidence: {np.mean([r[1] for r in ok]):.4f}")
+    print("\nInference completed!")
