@@ -18,15 +18,17 @@ P, I, F, LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 # name -> argument types (all return int); mirrors include/cogaim.h
 SIGNATURES = {
     "cogaim_version": [],
+    "cogaim_gemm_workspace_bytes": [],
+    "cogaim_set_gemm_algo": [I],
     "cogaim_im2col": [P, P, I, I, I, I, I, I, P],
-    "cogaim_gemm_patch_embed": [P, P, P, P, P, I, I, I, I, I, P],
+    "cogaim_gemm_patch_embed": [P, P, P, P, P, I, I, I, I, I, P, LL, P],
     "cogaim_cls_row": [P, P, P, I, I, I, P],
     "cogaim_layernorm": [P, P, P, P, I, I, F, I, P],
-    "cogaim_gemm_bias_half": [P, P, P, P, I, I, I, I, I, I, I, F, I, P],
-    "cogaim_gemm_vt": [P, P, P, P, I, I, I, I, I, I, I, I, P],
+    "cogaim_gemm_bias_half": [P, P, P, P, I, I, I, I, I, I, I, F, I, P, LL, P],
+    "cogaim_gemm_vt": [P, P, P, P, I, I, I, I, I, I, I, I, P, LL, P],
     "cogaim_mhsa_fwd": [P, P, P, I, I, I, I, I, I, P],
-    "cogaim_gemm_residual_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
-    "cogaim_gemm_bias_gelu_half": [P, P, P, P, I, I, I, I, I, I, I, P],
+    "cogaim_gemm_residual_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P, LL, P],
+    "cogaim_gemm_bias_gelu_half": [P, P, P, P, I, I, I, I, I, I, I, P, LL, P],
     "cogaim_focal_prep": [P, LL, P, P, P, I, I, I, I, P],
     "cogaim_gemm_batched_f32": [P, P, P, I, I, I, I, I, I, LL, LL, LL, I, I, P],
     "cogaim_focal_colsum_rows": [],
@@ -43,7 +45,7 @@ SIGNATURES = {
     "cogaim_heads": [P, I, P, P, P, P, P, P, P, P, I, P],
 }
 
-_NO_STATUS = {"cogaim_version", "cogaim_focal_colsum_rows", "cogaim_weighted_tokens_rows"}
+_NO_STATUS = {"cogaim_version", "cogaim_gemm_workspace_bytes", "cogaim_focal_colsum_rows", "cogaim_weighted_tokens_rows"}
 _lib = None
 
 
@@ -63,7 +65,7 @@ def lib() -> C.CDLL:
         for name, args in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes = args
-            fn.restype = I
+            fn.restype = LL if name == "cogaim_gemm_workspace_bytes" else I
         _lib = handle
     return _lib
 

@@ -27,8 +27,36 @@ struct GemmShape {
 // SWAP orientation: store4n(z, m, n0, v) gets C[m][n0..n0+3].
 // plain orientation: store4m(z, m0, n, v) gets C[m0..m0+3][n].
 
+template <class T>
+__device__ __forceinline__ void store_half16(T* p, const float (&y)[16]) {   // 16 contiguous 16-bit values, 32-B aligned
+  alignas(16) T h[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) h[i] = (T)y[i];
+  reinterpret_cast<uint4*>(p)[0] = reinterpret_cast<const uint4*>(h)[0];
+  reinterpret_cast<uint4*>(p)[1] = reinterpret_cast<const uint4*>(h)[1];
+}
+
+// store16n(z, m, n0, v): C[m][n0 + 4*q + j] = v[q][j], q, j = 0..3  (256x256 kernel: one lane owns 16 columns)
 template <class T> struct EpiBiasHalf {           // out16 = (acc + bias) [* scale for n < scale_cols]
+  static constexpr bool kWide = true;
   T* out; const float* bias; int ldc; int scale_cols; float scale; int M, N;
+  __device__ __forceinline__ void store16n(int, int m, int n0, const f32x4 (&v)[4]) const {
+    if (m >= M || n0 >= N) return;
+    if (n0 + 16 > N || (ldc & 7) || (scale_cols & 15)) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) store4n(0, m, n0 + 4 * q, v[q]);
+      return;
+    }
+    const float s = n0 < scale_cols ? scale : 1.0f;
+    float y[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + n0 + 4 * q);
+      y[4 * q] = (v[q][0] + b.x) * s; y[4 * q + 1] = (v[q][1] + b.y) * s;
+      y[4 * q + 2] = (v[q][2] + b.z) * s; y[4 * q + 3] = (v[q][3] + b.w) * s;
+    }
+    store_half16<T>(out + (size_t)m * ldc + n0, y);
+  }
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
     if (m >= M || n0 >= N) return;
     float s = n0 < scale_cols ? scale : 1.0f;
@@ -54,7 +82,24 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 template <class T> struct EpiBiasGeluHalf {
+  static constexpr bool kWide = true;
   T* out; const float* bias; int ldc; int M, N;
+  __device__ __forceinline__ void store16n(int, int m, int n0, const f32x4 (&v)[4]) const {
+    if (m >= M || n0 >= N) return;
+    if (n0 + 16 > N || (ldc & 7)) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) store4n(0, m, n0 + 4 * q, v[q]);
+      return;
+    }
+    float y[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + n0 + 4 * q);
+      y[4 * q] = gelu_erf(v[q][0] + b.x); y[4 * q + 1] = gelu_erf(v[q][1] + b.y);
+      y[4 * q + 2] = gelu_erf(v[q][2] + b.z); y[4 * q + 3] = gelu_erf(v[q][3] + b.w);
+    }
+    store_half16<T>(out + (size_t)m * ldc + n0, y);
+  }
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
     if (m >= M || n0 >= N) return;
     const float4 b = *reinterpret_cast<const float4*>(bias + n0);
@@ -63,7 +108,8 @@ template <class T> struct EpiBiasGeluHalf {
   }
 };
 
-struct EpiResidualF32 {                            // x += (acc + bias) * layerscale   (in place)
+struct EpiResidualF32 {
+  static constexpr bool kWide = false;                            // x += (acc + bias) * layerscale   (in place)
   float* x; const float* bias; const float* ls; int ldc; int M, N;
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
     if (m >= M || n0 >= N) return;
@@ -77,7 +123,8 @@ struct EpiResidualF32 {                            // x += (acc + bias) * layers
   }
 };
 
-struct EpiStoreF32 {                               // batched plain fp32 store (focal scores)
+struct EpiStoreF32 {
+  static constexpr bool kWide = false;                               // batched plain fp32 store (focal scores)
   float* out; int ldc; long long strideC; int M, N;
   __device__ __forceinline__ void store4n(int z, int m, int n0, f32x4 v) const {
     if (m >= M || n0 >= N) return;
@@ -85,7 +132,8 @@ struct EpiStoreF32 {                               // batched plain fp32 store (
   }
 };
 
-struct EpiPatchEmbed {                             // token row b*T+1+p = acc + bias + pos[1+p]
+struct EpiPatchEmbed {
+  static constexpr bool kWide = false;                             // token row b*T+1+p = acc + bias + pos[1+p]
   float* x; const float* bias; const float* pos; int D; int P; int M;   // P patches per image
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
     if (m >= M || n0 >= D) return;
@@ -98,6 +146,7 @@ struct EpiPatchEmbed {                             // token row b*T+1+p = acc + 
 };
 
 template <class T> struct EpiVT {                  // V^T[(b*H+h)*64 + d][t] (row length Tp), plain orientation
+  static constexpr bool kWide = false;
   T* vt; const float* bias; int T_, Tp, M, N;
   __device__ __forceinline__ void store4m(int, int m0, int n, f32x4 v) const {
     if (m0 >= M || n >= N) return;
@@ -107,6 +156,10 @@ template <class T> struct EpiVT {                  // V^T[(b*H+h)*64 + d][t] (ro
     T* row = vt + ((size_t)(b * H + (n >> 6)) * 64 + (n & 63)) * Tp;
     if (t + 3 < T_ && m0 + 3 < M && ((t & 3) == 0)) {
       *reinterpret_cast<Half4<T>*>(row + t) = to_half4<T>(v[0] + bi, v[1] + bi, v[2] + bi, v[3] + bi);
+    } else if (t + 3 < T_ && m0 + 3 < M && ((t & 1) == 0)) {      // image offset b*T is only 4-byte aligned
+      const Half4<T> h = to_half4<T>(v[0] + bi, v[1] + bi, v[2] + bi, v[3] + bi);
+      reinterpret_cast<uint32_t*>(row + t)[0] = reinterpret_cast<const uint32_t*>(&h)[0];
+      reinterpret_cast<uint32_t*>(row + t)[1] = reinterpret_cast<const uint32_t*>(&h)[1];
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -211,11 +264,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmShape g, Epi epi) {
     }
 }
 
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int OP_BYTES = 256 * BK * 2;        // 32 KiB per operand per stage
+constexpr int STAGE_BYTES = 2 * OP_BYTES;     // 64 KiB
+
+#include "gemm_persistent.h"
+
+int g_gemm_diag = 0;   // timing-only diagnostic variants (wrong results); never set outside tools/
+int g_gemm_algo = 2;   // 0: 128x128 kernel everywhere; 1: 256x256 ping-pong kernel, one tile per workgroup;
+                       // 2: persistent 256x256 ping-pong kernel (large problems only for 1 and 2)
+
 template <class T, class Epi, bool SWAP>
-int launch(const GemmShape& g, const Epi& epi, int batch, hipStream_t st, bool ragged_n = false) {
+int launch(const GemmShape& g, const Epi& epi, int batch, hipStream_t st, bool ragged_n = false,
+           void* workspace = nullptr, long long workspace_bytes = 0) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (!ragged_n && (g.N & 3) != 0) ||
       (g.lda & 7) != 0 || (g.ldw & 7) != 0)
     return COGAIM_EINVAL;
+  const int tm2 = (g.M + BM2 - 1) / BM2, tn2 = (g.N + BN2 - 1) / BN2;
+  const long long tiles2 = (long long)tm2 * tn2;
+  if (g_gemm_algo >= 1 && tiles2 * batch >= 128 && tiles2 * batch < (1 << 30))
+    return launch_persistent<T, Epi, SWAP>(g, epi, batch, st, workspace, workspace_bytes, g_gemm_algo == 2,
+                                           g_gemm_diag);
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   hipLaunchKernelGGL((gemm_kernel<T, Epi, SWAP>), dim3(tiles, batch), dim3(256), 0, st, g, epi);
   return COGAIM_LAUNCH_CHECK();
@@ -230,32 +299,35 @@ extern "C" {
 
 // out16[M,N] = (A * W^T + bias), columns [0, scale_cols) additionally multiplied by scale.
 int cogaim_gemm_bias_half(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
-                          int lda, int ldw, int ldc, int scale_cols, float scale, int dtype, void* stream) {
+                          int lda, int ldw, int ldc, int scale_cols, float scale, int dtype, void* workspace,
+                          long long workspace_bytes, void* stream) {
   GemmShape g{A, W, M, N, K, lda, ldw, 0, 0};
   if (ldc & 3) return COGAIM_EINVAL;
   return DISPATCH_T(dtype,
-      (launch<__bf16, EpiBiasHalf<__bf16>, true>(g, {(__bf16*)out, bias, ldc, scale_cols, scale, M, N}, 1, (hipStream_t)stream)),
-      (launch<_Float16, EpiBiasHalf<_Float16>, true>(g, {(_Float16*)out, bias, ldc, scale_cols, scale, M, N}, 1, (hipStream_t)stream)));
+      (launch<__bf16, EpiBiasHalf<__bf16>, true>(g, {(__bf16*)out, bias, ldc, scale_cols, scale, M, N}, 1, (hipStream_t)stream, false, workspace, workspace_bytes)),
+      (launch<_Float16, EpiBiasHalf<_Float16>, true>(g, {(_Float16*)out, bias, ldc, scale_cols, scale, M, N}, 1, (hipStream_t)stream, false, workspace, workspace_bytes)));
 }
 
 // out16[M,N] = gelu_erf(A * W^T + bias)
 int cogaim_gemm_bias_gelu_half(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
-                               int lda, int ldw, int ldc, int dtype, void* stream) {
+                               int lda, int ldw, int ldc, int dtype, void* workspace, long long workspace_bytes,
+                               void* stream) {
   GemmShape g{A, W, M, N, K, lda, ldw, 0, 0};
   if (ldc & 3) return COGAIM_EINVAL;
   return DISPATCH_T(dtype,
-      (launch<__bf16, EpiBiasGeluHalf<__bf16>, true>(g, {(__bf16*)out, bias, ldc, M, N}, 1, (hipStream_t)stream)),
-      (launch<_Float16, EpiBiasGeluHalf<_Float16>, true>(g, {(_Float16*)out, bias, ldc, M, N}, 1, (hipStream_t)stream)));
+      (launch<__bf16, EpiBiasGeluHalf<__bf16>, true>(g, {(__bf16*)out, bias, ldc, M, N}, 1, (hipStream_t)stream, false, workspace, workspace_bytes)),
+      (launch<_Float16, EpiBiasGeluHalf<_Float16>, true>(g, {(_Float16*)out, bias, ldc, M, N}, 1, (hipStream_t)stream, false, workspace, workspace_bytes)));
 }
 
 // x[M,N] += (A * W^T + bias) * layerscale      (fp32 residual stream, in place)
 int cogaim_gemm_residual_f32(const void* A, const void* W, const float* bias, const float* layerscale, float* x,
-                             int M, int N, int K, int lda, int ldw, int ldc, int dtype, void* stream) {
+                             int M, int N, int K, int lda, int ldw, int ldc, int dtype, void* workspace,
+                             long long workspace_bytes, void* stream) {
   GemmShape g{A, W, M, N, K, lda, ldw, 0, 0};
   if (ldc & 3) return COGAIM_EINVAL;
   EpiResidualF32 e{x, bias, layerscale, ldc, M, N};
-  return DISPATCH_T(dtype, (launch<__bf16, EpiResidualF32, true>(g, e, 1, (hipStream_t)stream)),
-                    (launch<_Float16, EpiResidualF32, true>(g, e, 1, (hipStream_t)stream)));
+  return DISPATCH_T(dtype, (launch<__bf16, EpiResidualF32, true>(g, e, 1, (hipStream_t)stream, false, workspace, workspace_bytes)),
+                    (launch<_Float16, EpiResidualF32, true>(g, e, 1, (hipStream_t)stream, false, workspace, workspace_bytes)));
 }
 
 // out32[z][M,N] = A[z] * W[z]^T for z < batch (strides in elements)
@@ -274,21 +346,35 @@ int cogaim_gemm_batched_f32(const void* A, const void* W, float* out, int M, int
 // Patch-embedding GEMM: rows are im2col'ed patches (B*P rows, K padded to a multiple of 64);
 // writes token rows 1..P of x[B, P+1, D] = acc + bias + pos[1+p].
 int cogaim_gemm_patch_embed(const void* cols, const void* W, const float* bias, const float* pos, float* x,
-                            int B, int P, int D, int K, int dtype, void* stream) {
+                            int B, int P, int D, int K, int dtype, void* workspace, long long workspace_bytes,
+                            void* stream) {
   GemmShape g{cols, W, B * P, D, K, K, K, 0, 0};
   EpiPatchEmbed e{x, bias, pos, D, P, B * P};
-  return DISPATCH_T(dtype, (launch<__bf16, EpiPatchEmbed, true>(g, e, 1, (hipStream_t)stream)),
-                    (launch<_Float16, EpiPatchEmbed, true>(g, e, 1, (hipStream_t)stream)));
+  return DISPATCH_T(dtype, (launch<__bf16, EpiPatchEmbed, true>(g, e, 1, (hipStream_t)stream, false, workspace, workspace_bytes)),
+                    (launch<_Float16, EpiPatchEmbed, true>(g, e, 1, (hipStream_t)stream, false, workspace, workspace_bytes)));
 }
 
 // V projection written transposed per head: vt[(b*H+h)*64+d][t] = A[b*T+t] . W[h*64+d] + bias, row length Tp.
 int cogaim_gemm_vt(const void* A, const void* W, const float* bias, void* vt, int B, int T, int D, int K, int lda,
-                   int ldw, int Tp, int dtype, void* stream) {
+                   int ldw, int Tp, int dtype, void* workspace, long long workspace_bytes, void* stream) {
   if ((D & 63) || Tp < T || (Tp & 3)) return COGAIM_EINVAL;
   GemmShape g{A, W, B * T, D, K, lda, ldw, 0, 0};
   return DISPATCH_T(dtype,
-      (launch<__bf16, EpiVT<__bf16>, false>(g, {(__bf16*)vt, bias, T, Tp, B * T, D}, 1, (hipStream_t)stream)),
-      (launch<_Float16, EpiVT<_Float16>, false>(g, {(_Float16*)vt, bias, T, Tp, B * T, D}, 1, (hipStream_t)stream)));
+      (launch<__bf16, EpiVT<__bf16>, false>(g, {(__bf16*)vt, bias, T, Tp, B * T, D}, 1, (hipStream_t)stream, false, workspace, workspace_bytes)),
+      (launch<_Float16, EpiVT<_Float16>, false>(g, {(_Float16*)vt, bias, T, Tp, B * T, D}, 1, (hipStream_t)stream, false, workspace, workspace_bytes)));
 }
+
+// Tuning knob: 0 = 128x128 kernel for every problem; 1 = 256x256 kernel, one tile per workgroup;
+// 2 (default) = persistent 256x256 kernel.  1 and 2 apply to large problems only.
+int cogaim_set_gemm_algo(int algo) {
+  if (algo >= 100) { g_gemm_diag = 1; g_gemm_algo = algo - 100; return COGAIM_OK; }   // tools/gemm_bench.py only
+  if (algo < 0 || algo > 2) return COGAIM_EINVAL;
+  g_gemm_algo = algo;
+  g_gemm_diag = 0;
+  return COGAIM_OK;
+}
+
+// Bytes of split-K workspace that let every GEMM entry point remove its partial last round of tiles.
+long long cogaim_gemm_workspace_bytes() { return 256LL * 32 * 512 * 16; }   // 256 partial tiles of 256 KiB
 
 }  // extern "C"

@@ -1,0 +1,306 @@
+// Persistent 256x256x64 ping-pong GEMM kernel (included by gemm.hip, inside its anonymous namespace).
+//
+// One 512-thread workgroup per CU walks a list of work items: whole 256x256 output tiles
+// first, then (optionally) one K-slice of a tile of the partial last round.  The K-tiles of
+// consecutive items form ONE stream: the LDS-DMA of the next K-tile is always in flight, also
+// across an item boundary, so only the very first K-tile of a workgroup pays the load latency
+// and the epilogue stores of one tile drain behind the math of the next.
+//
+// Per K-tile (64 deep) a wave runs four phases = four 64x32 quadrants of its 128x64 output,
+// each phase two barrier-delimited intervals:
+//     LOAD : ds_read this quadrant's fragments, issue 2 DMA pieces of the NEXT K-tile,
+//            wait for the LDS reads and for all but the 4 newest DMA pieces, barrier
+//     MATH : 16 x v_mfma_f32_16x16x32, barrier
+// Waves 4-7 run one interval behind waves 0-3 (one extra barrier at entry); each SIMD hosts
+// one wave of either group, so LDS/DMA traffic of one group overlaps the MFMAs of the other.
+//
+// DMA order within a K-tile, 2 pieces (1 KiB each) per wave per phase:
+//   phase 0: A rows first needed by phase 0 ("A-early", row mod 128 < 64)
+//   phase 1: W rows of phases 0 and 3      ("W-early", row mod 64 < 32, or row mod 16 < 8 when interleaved)
+//   phase 2: W rows of phases 1 and 2      ("W-late")
+//   phase 3: A rows of phases 2 and 3      ("A-late")
+// A piece is read two phases after the wait that retired it at the earliest, always behind a
+// barrier all waves passed after their own wait:
+//   wait at the end of LOAD 3 (all but W-late, A-late)   -> next tile's phase 0 reads A-early, W-early
+//   wait at the end of LOAD 0 (all but A-late, new A-early) -> phase 1 reads W-late
+//   wait at the end of LOAD 1                             -> phase 2 reads A-late
+// and a stage is overwritten only by DMA issued after the barrier that follows its last read
+// (LDS reads are waited for before that barrier).
+#pragma once
+
+// LDS chunk swizzles (row -> XOR on the 16-B chunk index, 0..7).  A fragments read rows fr, fr+16, ...;
+// W fragments read rows 16*(fr>>2) + 4*ni + (fr&3) (so that a lane ends up owning 16 adjacent output
+// columns), which needs a different function to stay bank-conflict free.
+__device__ __forceinline__ int swz_a(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int swz_w(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
+
+struct PersistSched {
+  int tiles_n;        // column tiles of one problem
+  int tiles_per_z;    // tiles of one problem (batched GEMM: tile index = z * tiles_per_z + local tile)
+  int n_full;         // tiles [0, n_full) are processed whole by workgroups [0, nblk_full), n_full % nblk_full == 0
+  int nblk_full;
+  int n_split;        // tiles [n_full, n_full + n_split) are cut into `slices` K-slices (1 = whole tile) ...
+  int slices;
+  int slice_block0;   // ... handled by workgroups [slice_block0, slice_block0 + n_split*slices), after their whole tiles
+  float* ws;          // [split tile][slice][32 fragments][512 threads] float4 (slices >= 2 only)
+};
+
+template <class T, class Epi, bool SWAP, int DIAG>
+__global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, PersistSched sc) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  using H = Half<T>;
+  using v8 = typename H::v8;
+  // WIDE: W fragment rows are interleaved so that a lane owns 16 adjacent output columns (16-bit
+  // outputs: two 16-B stores per row instead of four 8-B ones).  fp32 outputs keep 4 columns per
+  // lane and fragment, which makes every store instruction cover 64 contiguous bytes per row.
+  constexpr bool WIDE = SWAP && Epi::kWide;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = g.K / BK;
+  const int bid = blockIdx.x;
+  const int full_per_block = bid < sc.nblk_full ? sc.n_full / sc.nblk_full : 0;
+  const int sb = bid - sc.slice_block0;
+  const bool has_slice = sb >= 0 && sb < sc.n_split * sc.slices;
+  const int n_items = full_per_block + (has_slice ? 1 : 0);
+  if (n_items == 0) return;
+  const T* const A0 = reinterpret_cast<const T*>(g.A);
+  const T* const W0 = reinterpret_cast<const T*>(g.W);
+
+  // ---- work items ----------------------------------------------------------------------------
+  struct Item { int tile, kt0, kt1, slice; };
+  auto item_at = [&](int j) -> Item {
+    if (j < full_per_block) return Item{j * sc.nblk_full + xcd_remap(bid, sc.nblk_full), 0, nk, -1};
+    const int t = sc.n_full + sb / sc.slices, s = sb % sc.slices;
+    return Item{t, (int)((long long)nk * s / sc.slices), (int)((long long)nk * (s + 1) / sc.slices),
+                sc.slices == 1 ? -1 : s};
+  };
+
+  // ---- DMA side: a cursor over the flat K-tile stream -----------------------------------------
+  // piece ids per wave: A-early / A-late / W-early / W-late, two each
+  int pAe[2], pAl[2], pWe[2], pWl[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = 2 * wave + u;                         // 0..15
+    pAe[u] = e < 8 ? e : e + 8;                         // rows (p*8) mod 128 < 64
+    pAl[u] = pAe[u] + 8;
+    if constexpr (WIDE) {
+      pWe[u] = 2 * e;                                   // rows (p*8) mod 16 < 8
+      pWl[u] = 2 * e + 1;
+    } else {
+      pWe[u] = (e >> 2) * 8 + (e & 3);                  // rows (p*8) mod 64 < 32
+      pWl[u] = pWe[u] + 4;
+    }
+  }
+  const T* sAe[2]; const T* sAl[2]; const T* sWe[2]; const T* sWl[2];
+  int d_item = 0, d_kt = 0, d_kt1 = 0;                  // DMA cursor
+  bool d_valid = true;
+  auto dma_set_item = [&](int j) {
+    const Item it = item_at(j);
+    const int z = it.tile / sc.tiles_per_z, lt = it.tile - z * sc.tiles_per_z;
+    const int tm = lt / sc.tiles_n, tn = lt - tm * sc.tiles_n;
+    const T* A = A0 + z * g.strideA;
+    const T* W = W0 + z * g.strideW;
+    d_kt = it.kt0; d_kt1 = it.kt1;
+    auto src = [&](const T* base, int ld, int row0, int limit, int piece, bool w_op) {
+      const int r = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((w_op && WIDE) ? swz_w(r) : swz_a(r));
+      int gr = row0 + r; gr = gr < limit ? gr : limit - 1;
+      return base + (size_t)gr * ld + c * 8;
+    };
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      sAe[u] = src(A, g.lda, tm * BM2, g.M, pAe[u], false);
+      sAl[u] = src(A, g.lda, tm * BM2, g.M, pAl[u], false);
+      sWe[u] = src(W, g.ldw, tn * BN2, g.N, pWe[u], true);
+      sWl[u] = src(W, g.ldw, tn * BN2, g.N, pWl[u], true);
+    }
+  };
+  auto dma_advance = [&]() {        // after the 4 phases of one K-tile have issued its pieces
+    if (++d_kt >= d_kt1) {
+      if (++d_item < n_items) dma_set_item(d_item); else d_valid = false;
+    }
+  };
+#define DMA2(srcs_, pieces_, op_off_, stage_)                                                        \
+  do {                                                                                               \
+    glds16(srcs_[0] + (size_t)d_kt * BK, smem + (stage_) * STAGE_BYTES + (op_off_) + pieces_[0] * 1024); \
+    glds16(srcs_[1] + (size_t)d_kt * BK, smem + (stage_) * STAGE_BYTES + (op_off_) + pieces_[1] * 1024); \
+  } while (0)
+
+  // ---- math side --------------------------------------------------------------------------------
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int c0 = (fq ^ swz_a(fr)) << 4;                               // A k-chunk of k32 step 0; step 1 is c0 ^ 64
+  const int wrow = WIDE ? 16 * (fr >> 2) + (fr & 3) : fr;                // W row of this lane within the wave's 64
+  constexpr int W_NI_STRIDE = WIDE ? 4 * 128 : 16 * 128;                 // bytes between the rows of fragments ni, ni+1
+  const int cw0 = (fq ^ (WIDE ? swz_w(wrow) : swz_a(wrow))) << 4;
+  const char* const a_base = smem + (wr * 128 + fr) * 128;               // + mi*2048
+  const char* const w_base = smem + OP_BYTES + (wc * 64 + wrow) * 128;   // + ni*W_NI_STRIDE
+
+#define WAIT_LOAD(n_) asm volatile("s_waitcnt vmcnt(" #n_ ") lgkmcnt(0)" ::: "memory")
+#define BARRIER()                                  \
+  do {                                             \
+    __builtin_amdgcn_sched_barrier(0);             \
+    __builtin_amdgcn_s_barrier();                  \
+    __builtin_amdgcn_sched_barrier(0);             \
+  } while (0)
+#define LOAD_A(dst_, mh_)                                                                            \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                   \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                   \
+    dst_[s_][i_] = *reinterpret_cast<const v8*>(a_base + boff + ((mh_) * 4 + i_) * 2048 + (s_ ? (c0 ^ 64) : c0))
+#define LOAD_W(dst_, nh_)                                                                            \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                   \
+  _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                   \
+    dst_[s_][j_] = *reinterpret_cast<const v8*>(w_base + boff + ((nh_) * 2 + j_) * W_NI_STRIDE + (s_ ? (cw0 ^ 64) : cw0))
+#define MATH(af_, wf_, mh_, nh_)                                                                     \
+  do {                                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                   \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                 \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                 \
+      acc[(mh_) * 4 + i_][(nh_) * 2 + j_] = SWAP                                                     \
+          ? H::mfma16(wf_[s_][j_], af_[s_][i_], acc[(mh_) * 4 + i_][(nh_) * 2 + j_])                 \
+          : H::mfma16(af_[s_][i_], wf_[s_][j_], acc[(mh_) * 4 + i_][(nh_) * 2 + j_]);                \
+    __builtin_amdgcn_s_setprio(0);                                                                   \
+  } while (0)
+
+  // ---- prologue: the first K-tile of the stream into stage 0 --------------------------------------
+  dma_set_item(0);
+  DMA2(sAe, pAe, 0, 0);
+  DMA2(sWe, pWe, OP_BYTES, 0);
+  DMA2(sWl, pWl, OP_BYTES, 0);
+  DMA2(sAl, pAl, 0, 0);
+  dma_advance();
+  WAIT_LOAD(4);
+  BARRIER();
+  if (wr == 1) BARRIER();          // waves 4-7 trail by one interval
+
+  int flat = 0;                    // K-tiles consumed so far: stage = flat & 1
+  for (int j = 0; j < n_items; ++j) {
+    const Item it = item_at(j);
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = it.kt0; kt < it.kt1; ++kt, ++flat) {
+      const int st = flat & 1;
+      const int boff = st * STAGE_BYTES;
+      const bool more = (DIAG == 1) ? false : d_valid;       // wave-uniform
+      v8 af[2][4], wf0[2][2], wf1[2][2];
+      // ---- phase 0: quadrant (m 0-63, n 0-31)
+      LOAD_A(af, 0);
+      LOAD_W(wf0, 0);
+      if (more) { DMA2(sAe, pAe, 0, st ^ 1); WAIT_LOAD(4); } else { WAIT_LOAD(2); }
+      BARRIER();
+      MATH(af, wf0, 0, 0);
+      BARRIER();
+      // ---- phase 1: (m 0-63, n 32-63)
+      LOAD_W(wf1, 1);
+      if (more) { DMA2(sWe, pWe, OP_BYTES, st ^ 1); WAIT_LOAD(4); } else { WAIT_LOAD(0); }
+      BARRIER();
+      MATH(af, wf1, 0, 1);
+      BARRIER();
+      // ---- phase 2: (m 64-127, n 32-63)
+      LOAD_A(af, 1);
+      if (more) { DMA2(sWl, pWl, OP_BYTES, st ^ 1); WAIT_LOAD(4); } else { WAIT_LOAD(0); }
+      BARRIER();
+      MATH(af, wf1, 1, 1);
+      BARRIER();
+      // ---- phase 3: (m 64-127, n 0-31)
+      if (more) { DMA2(sAl, pAl, 0, st ^ 1); dma_advance(); WAIT_LOAD(4); }
+      BARRIER();
+      MATH(af, wf0, 1, 0);
+      BARRIER();
+    }
+
+    const int z = it.tile / sc.tiles_per_z, lt = it.tile - z * sc.tiles_per_z;
+    const int tm = lt / sc.tiles_n, tn = lt - tm * sc.tiles_n;
+    if (it.slice < 0) {
+      const int m_base = tm * BM2 + wr * 128, n_base = tn * BN2 + wc * 64;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if constexpr (WIDE) {
+          epi.store16n(z, m_base + 16 * i + fr, n_base + 16 * fq, acc[i]);
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            if constexpr (SWAP) epi.store4n(z, m_base + 16 * i + fr, n_base + 16 * jj + 4 * fq, acc[i][jj]);
+            else epi.store4m(z, m_base + 16 * i + 4 * fq, n_base + 16 * jj + fr, acc[i][jj]);
+          }
+        }
+      }
+    } else {
+      float4* out = reinterpret_cast<float4*>(sc.ws) +
+                    ((size_t)((it.tile - sc.n_full) * sc.slices + it.slice) * 32) * 512 + tid;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          out[(size_t)(i * 4 + jj) * 512] = make_float4(acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]);
+    }
+  }
+  if (wr == 0) BARRIER();          // match the extra barrier of the trailing group
+
+#undef DMA2
+#undef WAIT_LOAD
+#undef BARRIER
+#undef LOAD_A
+#undef LOAD_W
+#undef MATH
+}
+
+// Sums the K-slice partials of the split tiles in slice order and runs the epilogue
+// (one accumulator fragment per thread: blockIdx.y = mi*4 + ni).
+template <class Epi, bool SWAP>
+__global__ __launch_bounds__(512) void gemm256p_fixup_kernel(Epi epi, PersistSched sc) {
+  constexpr bool WIDE = SWAP && Epi::kWide;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int st = blockIdx.x, i = blockIdx.y >> 2, jj = blockIdx.y & 3;
+  const int tile = sc.n_full + st;
+  const int z = tile / sc.tiles_per_z, lt = tile - z * sc.tiles_per_z;
+  const int tm = lt / sc.tiles_n, tn = lt - tm * sc.tiles_n;
+  const float4* in = reinterpret_cast<const float4*>(sc.ws) + ((size_t)st * sc.slices * 32 + blockIdx.y) * 512 + tid;
+  float4 a = in[0];
+  for (int s = 1; s < sc.slices; ++s) {
+    const float4 b = in[(size_t)s * 32 * 512];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  const f32x4 v{a.x, a.y, a.z, a.w};
+  const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, fq = lane >> 4;
+  const int m_base = tm * BM2 + wr * 128, n_base = tn * BN2 + wc * 64;
+  if constexpr (WIDE) epi.store4n(z, m_base + 16 * i + fr, n_base + 16 * fq + 4 * jj, v);
+  else if constexpr (SWAP) epi.store4n(z, m_base + 16 * i + fr, n_base + 16 * jj + 4 * fq, v);
+  else epi.store4m(z, m_base + 16 * i + 4 * fq, n_base + 16 * jj + fr, v);
+}
+
+// Host side.  persistent: at most one workgroup per CU, each walking whole rounds of tiles, the
+// remainder K-split over the first workgroups.  Otherwise one workgroup per whole tile plus extra
+// workgroups for the K-slices.  Without a workspace the remainder runs as whole tiles.
+template <class T, class Epi, bool SWAP>
+int launch_persistent(const GemmShape& g, const Epi& epi, int batch, hipStream_t st, void* workspace,
+                      long long workspace_bytes, bool persistent, int diag) {
+  constexpr int CUS = 256;
+  const int tm2 = (g.M + BM2 - 1) / BM2, tn2 = (g.N + BN2 - 1) / BN2;
+  const int tiles_per_z = tm2 * tn2, tiles = tiles_per_z * batch, nk = g.K / BK;
+  const int lanes = tiles < CUS ? tiles : CUS;                 // concurrent workgroups
+  PersistSched sc{tn2, tiles_per_z, (tiles / lanes) * lanes, 0, 0, 1, 0, (float*)workspace};
+  const int rem = tiles - sc.n_full;
+  if (rem > 0) {
+    sc.n_split = rem;
+    int slices = lanes / rem;
+    if (slices > nk) slices = nk;
+    if (slices > 8) slices = 8;          // more slices only lengthen the fix-up pass
+    if (slices >= 2 && workspace && (long long)rem * slices * 32 * 512 * 16 <= workspace_bytes) sc.slices = slices;
+  }
+  sc.nblk_full = persistent ? lanes : sc.n_full;
+  sc.slice_block0 = persistent ? 0 : sc.nblk_full;
+  const int grid = persistent ? lanes : sc.nblk_full + sc.n_split * sc.slices;
+  if (diag == 1)
+    hipLaunchKernelGGL((gemm256p_kernel<T, Epi, SWAP, 1>), dim3(grid), dim3(512), 0, st, g, epi, sc);
+  else
+    hipLaunchKernelGGL((gemm256p_kernel<T, Epi, SWAP, 0>), dim3(grid), dim3(512), 0, st, g, epi, sc);
+  if (sc.n_split && sc.slices >= 2)
+    hipLaunchKernelGGL((gemm256p_fixup_kernel<Epi, SWAP>), dim3(sc.n_split, 32), dim3(512), 0, st, epi, sc);
+  return COGAIM_LAUNCH_CHECK();
+}

@@ -361,6 +361,7 @@ class CognitiveAimModel(nn.Module):
             "h": torch.empty(M, D, **h16), "qk": torch.empty(M, 2 * D, **h16),
             "vt": torch.zeros(B * H * 64 * Tp, **h16), "ctx": torch.empty(M, D, **h16),
             "big": torch.empty(big_bytes, device=dev, dtype=torch.uint8),
+            "gemm_ws": torch.empty(call("cogaim_gemm_workspace_bytes"), device=dev, dtype=torch.uint8),
             "rmax": torch.empty(B, N, **f32), "rinv": torch.empty(B, N, **f32),
             "part": torch.empty(B * nblk * N, **f32), "attn": torch.empty(B, N, **f32),
             "scale": torch.empty(2, B, N, **f32), "stats": torch.empty(B, 2, device=dev, dtype=torch.float64),
@@ -397,20 +398,21 @@ class CognitiveAimModel(nn.Module):
         N, T, M, Tp = ws["N"], ws["T"], ws["M"], ws["Tp"]
         pos = self._table("pos", gh, gw)
         x, h, qk, vt, ctx, big = (ws[k].data_ptr() for k in ("x", "h", "qk", "vt", "ctx", "big"))
+        gw, gwb = ws["gemm_ws"].data_ptr(), ws["gemm_ws"].numel()
         call("cogaim_im2col", images.data_ptr(), big, B, Hi, Wi, p, pk["pe_kp"], dt, st)
         call("cogaim_cls_row", ptr(pk["cls"]), ptr(pos), x, B, T, D, st)
-        call("cogaim_gemm_patch_embed", big, ptr(pk["pe_w"]), ptr(pk["pe_b"]), ptr(pos), x, B, N, D, pk["pe_kp"], dt, st)
+        call("cogaim_gemm_patch_embed", big, ptr(pk["pe_w"]), ptr(pk["pe_b"]), ptr(pos), x, B, N, D, pk["pe_kp"], dt, gw, gwb, st)
         qscale = 64 ** -0.5 * LOG2E
         eps = self.layer_norm_eps
         for L in pk["layers"]:
             call("cogaim_layernorm", x, ptr(L["g1"]), ptr(L["b1"]), h, M, D, eps, dt, st)
-            call("cogaim_gemm_bias_half", h, ptr(L["wqk"]), ptr(L["bqk"]), qk, M, 2 * D, D, D, D, 2 * D, D, qscale, dt, st)
-            call("cogaim_gemm_vt", h, ptr(L["wv"]), ptr(L["bv"]), vt, B, T, D, D, D, D, Tp, dt, st)
+            call("cogaim_gemm_bias_half", h, ptr(L["wqk"]), ptr(L["bqk"]), qk, M, 2 * D, D, D, D, 2 * D, D, qscale, dt, gw, gwb, st)
+            call("cogaim_gemm_vt", h, ptr(L["wv"]), ptr(L["bv"]), vt, B, T, D, D, D, D, Tp, dt, gw, gwb, st)
             call("cogaim_mhsa_fwd", qk, vt, ctx, B, T, H, Tp, 2 * D, dt, st)
-            call("cogaim_gemm_residual_f32", ctx, ptr(L["wo"]), ptr(L["bo"]), ptr(L["ls1"]), x, M, D, D, D, D, D, dt, st)
+            call("cogaim_gemm_residual_f32", ctx, ptr(L["wo"]), ptr(L["bo"]), ptr(L["ls1"]), x, M, D, D, D, D, D, dt, gw, gwb, st)
             call("cogaim_layernorm", x, ptr(L["g2"]), ptr(L["b2"]), h, M, D, eps, dt, st)
-            call("cogaim_gemm_bias_gelu_half", h, ptr(L["w1"]), ptr(L["bf1"]), big, M, 4 * D, D, D, D, 4 * D, dt, st)
-            call("cogaim_gemm_residual_f32", big, ptr(L["w2"]), ptr(L["bf2"]), ptr(L["ls2"]), x, M, D, 4 * D, 4 * D, 4 * D, D, dt, st)
+            call("cogaim_gemm_bias_gelu_half", h, ptr(L["w1"]), ptr(L["bf1"]), big, M, 4 * D, D, D, D, 4 * D, dt, gw, gwb, st)
+            call("cogaim_gemm_residual_f32", big, ptr(L["w2"]), ptr(L["bf2"]), ptr(L["ls2"]), x, M, D, 4 * D, 4 * D, 4 * D, D, dt, gw, gwb, st)
         call("cogaim_layernorm", x, ptr(pk["gf"]), ptr(pk["bf"]), ws["tokens"].data_ptr(), M, D, eps, 2, st)
 
     def _focal(self, B: int, ws: dict):
@@ -431,7 +433,8 @@ class CognitiveAimModel(nn.Module):
             s_in = None if i == 0 else ws["scale"][i % 2].data_ptr()
             s_out = None if i == I - 1 else ws["scale"][(i + 1) % 2].data_ptr()
             call("cogaim_focal_prep", tok, tstride, s_in, ptr(pe), h, B, N, D, dt, st)
-            call("cogaim_gemm_bias_half", h, ptr(f["wqk"]), ptr(f["bqk"]), qk, B * N, 2 * D, D, D, D, 2 * D, D, sscale, dt, st)
+            call("cogaim_gemm_bias_half", h, ptr(f["wqk"]), ptr(f["bqk"]), qk, B * N, 2 * D, D, D, D, 2 * D, D, sscale, dt,
+                 ws["gemm_ws"].data_ptr(), ws["gemm_ws"].numel(), st)
             call("cogaim_gemm_batched_f32", qk, qk + D * esz, S, N, N, D, 2 * D, 2 * D, ldS,
                  N * 2 * D, N * 2 * D, N * ldS, B, dt, st)
             call("cogaim_focal_softmax_stats_colsum", S, ldS, N * ldS, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["part"]), B, N, st)

@@ -27,6 +27,15 @@ extern "C" {
 
 int cogaim_version(void);
 
+/* The GEMM entry points take an optional `workspace` (device memory, `workspace_bytes` long;
+ * NULL/0 allowed).  With at least cogaim_gemm_workspace_bytes() bytes they split the tiles of
+ * a partial last round along K over the idle CUs (fp32 partials, summed in fixed order: results
+ * stay bit-reproducible).  No counterpart in the reference. */
+long long cogaim_gemm_workspace_bytes(void);
+/* tuning knob: 0 = 128x128-tile kernel for every problem, 1 = 256x256 kernel (one tile per workgroup),
+ * 2 (default) = persistent 256x256 kernel; 1 and 2 apply to large problems only */
+int cogaim_set_gemm_algo(int algo);
+
 /* ---- DINOv2 backbone --------------------------------------------------- */
 
 /* hf:139-149 Dinov2PatchEmbeddings (Conv2d k=14,s=14 as an im2col GEMM), step 1:
@@ -37,7 +46,7 @@ int cogaim_im2col(const float* images, void* cols, int B, int H, int W, int patc
 /* hf:97-116 Dinov2Embeddings, step 2: x[b, 1+p, :] = cols[b*P+p] . W^T + bias + pos[1+p]
  * (x fp32 [B, P+1, D], W 16-bit [D, Kp], pos fp32 [P+1, D] already interpolated, hf:57-95). */
 int cogaim_gemm_patch_embed(const void* cols, const void* W, const float* bias, const float* pos, float* x, int B,
-                            int P, int D, int K, int dtype, void* stream);
+                            int P, int D, int K, int dtype, void* workspace, long long workspace_bytes, void* stream);
 
 /* hf:108-112: x[b, 0, :] = cls_token + pos[0]. */
 int cogaim_cls_row(const float* cls, const float* pos, float* x, int B, int T, int D, void* stream);
@@ -51,13 +60,14 @@ int cogaim_layernorm(const float* x, const float* gamma, const float* beta, void
  * [0, scale_cols) times `scale` (the softmax scale hf:196 folded into Q).  Also the focal
  * stream's query_proj/key_proj (src/model.py:192-193, scale 1/sqrt(D//8) of :69,197). */
 int cogaim_gemm_bias_half(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int lda,
-                          int ldw, int ldc, int scale_cols, float scale, int dtype, void* stream);
+                          int ldw, int ldc, int scale_cols, float scale, int dtype, void* workspace,
+                          long long workspace_bytes, void* stream);
 
 /* hf:201,212 value Linear, written transposed per head for the attention kernel:
  * vt[(b*H+h)*64 + d][t] = A[b*T+t] . W[h*64+d] + bias[h*64+d];  rows are Tp long (Tp >= T, multiple of 64);
  * columns t >= T are never written and must be finite (zero them once). */
 int cogaim_gemm_vt(const void* A, const void* W, const float* bias, void* vt, int B, int T, int D, int K, int lda,
-                   int ldw, int Tp, int dtype, void* stream);
+                   int ldw, int Tp, int dtype, void* workspace, long long workspace_bytes, void* stream);
 
 /* hf:153-178 softmax(Q K^T * dh^-0.5) V for all heads (dh = 64), flash style.
  * qk 16-bit [B*T, ldqk]: Q pre-multiplied by dh^-0.5*log2(e) in cols [0,D), K in [D,2D);
@@ -68,11 +78,12 @@ int cogaim_mhsa_fwd(const void* qk, const void* vt, void* ctx, int B, int T, int
 /* hf:246-252 output dense + hf:277-278 LayerScale + hf:370 residual, and the same for
  * fc2 (hf:296, 375-378):  x[M,N] += (A . W^T + bias) * layerscale, in place, x fp32. */
 int cogaim_gemm_residual_f32(const void* A, const void* W, const float* bias, const float* layerscale, float* x, int M,
-                             int N, int K, int lda, int ldw, int ldc, int dtype, void* stream);
+                             int N, int K, int lda, int ldw, int ldc, int dtype, void* workspace,
+                             long long workspace_bytes, void* stream);
 
 /* hf:293-295 fc1 + exact (erf) GELU: out16[M,N] = gelu(A . W^T + bias). */
 int cogaim_gemm_bias_gelu_half(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int lda,
-                               int ldw, int ldc, int dtype, void* stream);
+                               int ldw, int ldc, int dtype, void* workspace, long long workspace_bytes, void* stream);
 
 /* ---- focal stream (src/model.py:128-313, 391-455) ----------------------- */
 

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     text = open(os.path.join(ROOT, "include", "cogaim.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return re.findall(r"\bint\s+(cogaim_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S)
+    return re.findall(r"\b(?:int|long long)\s+(cogaim_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S)
 
 
 def test_library_exports_every_declared_symbol():

@@ -21,6 +21,16 @@ def _dev():
     torch.cuda.synchronize()
 
 
+_WS = {}
+
+
+def WS():
+    """(pointer, bytes) of the optional split-K workspace of the GEMM entry points."""
+    if "t" not in _WS:
+        _WS["t"] = torch.empty(call("cogaim_gemm_workspace_bytes"), device="cuda", dtype=torch.uint8)
+    return _WS["t"].data_ptr(), _WS["t"].numel()
+
+
 def rnd(*shape, dtype=torch.float32, scale=1.0):
     return (torch.randn(*shape, device="cuda") * scale).to(dtype)
 
@@ -31,7 +41,7 @@ def test_gemm_bias_half(dtype, M, N, K):
     di, tdt = DT[dtype]
     A, W, bias = rnd(M, K, dtype=tdt), rnd(N, K, dtype=tdt, scale=K ** -0.5), rnd(N)
     out = torch.full((M, N), float("nan"), device="cuda", dtype=tdt)
-    call("cogaim_gemm_bias_half", ptr(A), ptr(W), ptr(bias), ptr(out), M, N, K, K, K, N, N // 2, 0.25, di, stream_ptr())
+    call("cogaim_gemm_bias_half", ptr(A), ptr(W), ptr(bias), ptr(out), M, N, K, K, K, N, N // 2, 0.25, di, *WS(), stream_ptr())
     ref = A.float() @ W.float().t() + bias
     ref[:, : N // 2] *= 0.25
     tol = 2 ** -8 if dtype == "bf16" else 2 ** -10
@@ -45,23 +55,23 @@ def test_gemm_residual_and_gelu(dtype):
     A, W, bias, ls = rnd(M, K, dtype=tdt), rnd(N, K, dtype=tdt, scale=K ** -0.5), rnd(N), 1 + 0.1 * rnd(N)
     x0 = rnd(M, N)
     x = x0.clone()
-    call("cogaim_gemm_residual_f32", ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(x), M, N, K, K, K, N, di, stream_ptr())
+    call("cogaim_gemm_residual_f32", ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(x), M, N, K, K, K, N, di, *WS(), stream_ptr())
     ref = x0 + (A.float() @ W.float().t() + bias) * ls
     assert torch.allclose(x, ref, rtol=1e-4, atol=1e-4), float((x - ref).abs().max())
     M, N, K = 515, 3072, 768
     A, W, bias = rnd(M, K, dtype=tdt), rnd(N, K, dtype=tdt, scale=K ** -0.5), rnd(N)
     out = torch.empty(M, N, device="cuda", dtype=tdt)
-    call("cogaim_gemm_bias_gelu_half", ptr(A), ptr(W), ptr(bias), ptr(out), M, N, K, K, K, N, di, stream_ptr())
+    call("cogaim_gemm_bias_gelu_half", ptr(A), ptr(W), ptr(bias), ptr(out), M, N, K, K, K, N, di, *WS(), stream_ptr())
     ref = torch.nn.functional.gelu(A.float() @ W.float().t() + bias)
     tol = 2 ** -8 if dtype == "bf16" else 2 ** -10
     assert torch.allclose(out.float(), ref, rtol=tol, atol=tol)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("N", [100, 1369])
-def test_gemm_batched_scores(dtype, N):
+@pytest.mark.parametrize("N,B", [(100, 3), (1369, 3), (1369, 9)])
+def test_gemm_batched_scores(dtype, N, B):
     di, tdt = DT[dtype]
-    B, D = 3, 768
+    D = 768
     ldS = (N + 127) // 128 * 128
     qk = rnd(B * N, 2 * D, dtype=tdt, scale=0.5)
     S = torch.zeros(B, N, ldS, device="cuda")
@@ -81,7 +91,7 @@ def test_gemm_vt(dtype, B, T):
     Tp = (T + 63) // 64 * 64
     A, W, bias = rnd(B * T, D, dtype=tdt), rnd(D, D, dtype=tdt, scale=D ** -0.5), rnd(D)
     vt = torch.zeros(B * H * 64 * Tp, device="cuda", dtype=tdt)
-    call("cogaim_gemm_vt", ptr(A), ptr(W), ptr(bias), ptr(vt), B, T, D, D, D, D, Tp, di, stream_ptr())
+    call("cogaim_gemm_vt", ptr(A), ptr(W), ptr(bias), ptr(vt), B, T, D, D, D, D, Tp, di, *WS(), stream_ptr())
     ref = (A.float() @ W.float().t() + bias).view(B, T, H, 64).permute(0, 2, 3, 1)   # [B,H,64,T]
     got = vt.view(B, H, 64, Tp)
     tol = 2 ** -8 if dtype == "bf16" else 2 ** -10
@@ -105,7 +115,7 @@ def test_patch_embed(dtype, size):
     x = torch.full((B, T, D), float("nan"), device="cuda")
     call("cogaim_im2col", ptr(img), ptr(cols), B, size, size, p, Kp, di, stream_ptr())
     call("cogaim_cls_row", ptr(cls), ptr(pos), ptr(x), B, T, D, stream_ptr())
-    call("cogaim_gemm_patch_embed", ptr(cols), ptr(wp), ptr(bias), ptr(pos), ptr(x), B, P, D, Kp, di, stream_ptr())
+    call("cogaim_gemm_patch_embed", ptr(cols), ptr(wp), ptr(bias), ptr(pos), ptr(x), B, P, D, Kp, di, *WS(), stream_ptr())
     conv = torch.nn.functional.conv2d(img.to(tdt).float(), w.to(tdt).float(), bias, stride=p).flatten(2).transpose(1, 2)
     ref = torch.cat([cls.expand(B, 1, D), conv], 1) + pos
     assert torch.allclose(x, ref, rtol=1e-4, atol=1e-4), float((x - ref).abs().max())
@@ -206,3 +216,39 @@ def test_guided_attention_kernel(N):
         call("cogaim_guided_attention", ptr(a), ptr(mask), ptr(out), B, N, 0.7, 0.05, stream_ptr())
         ref = O.guided_attention(a.cpu(), mask.cpu())
         assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=1e-10)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K", [(43840, 768, 768), (40000, 1536, 128), (70000, 768, 3072), (33000, 1280, 64)])
+def test_large_gemm_kernels_agree(dtype, M, N, K):
+    """Large problems take the 256x256 ping-pong kernel (with the split-K tail when a workspace is given);
+    all three routes must agree with fp32 matmul and with each other (bitwise between split / no split is
+    not required: the K-slices change the summation order)."""
+    di, tdt = DT[dtype]
+    A, W, bias, ls = rnd(M, K, dtype=tdt), rnd(N, K, dtype=tdt, scale=K ** -0.5), rnd(N), 1 + 0.1 * rnd(N)
+    x0 = rnd(M, N)
+    ref = x0 + (A.float() @ W.float().t() + bias) * ls
+    outs = []
+    for algo, ws in ((0, (None, 0)), (1, (None, 0)), (1, WS()), (2, (None, 0)), (2, WS())):
+        call("cogaim_set_gemm_algo", algo)
+        x = x0.clone()
+        call("cogaim_gemm_residual_f32", ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(x), M, N, K, K, K, N, di, *ws, stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.allclose(x, ref, rtol=1e-4, atol=2e-4), (algo, float((x - ref).abs().max()))
+        outs.append(x)
+    call("cogaim_set_gemm_algo", 2)
+    again = x0.clone()
+    call("cogaim_gemm_residual_f32", ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(again), M, N, K, K, K, N, di, *WS(), stream_ptr())
+    assert torch.equal(again, outs[4])          # deterministic
+    out16 = torch.empty(M, N, device="cuda", dtype=tdt)
+    call("cogaim_gemm_bias_gelu_half", ptr(A), ptr(W), ptr(bias), ptr(out16), M, N, K, K, K, N, di, *WS(), stream_ptr())
+    refg = torch.nn.functional.gelu(A.float() @ W.float().t() + bias)
+    tol = 2 ** -8 if dtype == "bf16" else 2 ** -10
+    assert torch.allclose(out16.float(), refg, rtol=tol, atol=tol)
+    if N % 64 == 0 and K >= 64:
+        B, T = 8, M // 8
+        Tp = (T + 63) // 64 * 64
+        vt = torch.zeros(B * (N // 64) * 64 * Tp, device="cuda", dtype=tdt)
+        call("cogaim_gemm_vt", ptr(A), ptr(W), ptr(bias), ptr(vt), B, T, N, K, K, K, Tp, di, *WS(), stream_ptr())
+        refv = (A[: B * T].float() @ W.float().t() + bias).view(B, T, N // 64, 64).permute(0, 2, 3, 1)
+        assert torch.allclose(vt.view(B, N // 64, 64, Tp)[..., :T].float(), refv, rtol=tol, atol=tol)
