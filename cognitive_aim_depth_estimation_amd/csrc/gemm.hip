@@ -24,11 +24,20 @@ struct GemmShape {
 };
 
 // ---- epilogues -------------------------------------------------------------
-// SWAP orientation: store4n(z, m, n0, v) gets C[m][n0..n0+3].
-// plain orientation: store4m(z, m0, n, v) gets C[m0..m0+3][n].
+// Every epilogue is split into loads and stores so that a kernel can issue ALL loads of a
+// tile (column constants, residual values) before the first store: a store to the output may
+// alias a later load as far as the compiler can tell, so loads written after stores are
+// serialised behind them, one memory round trip per fragment.
+//   SWAP orientation (a lane owns 4 or 16 consecutive columns of one row):
+//     load_cols(n0, b, l)            column constants of columns n0..n0+3 (bias, LayerScale)
+//     load_res(z, m, n0)             per-element addend (kResidual epilogues only)
+//     finish4n(z, m, n0, acc, b, l, r)
+//     finish16n(z, m, n0, acc[4], b[4])      kWide epilogues: 16 adjacent columns per lane
+//     store4n(z, m, n0, acc)         all of the above for one fragment (128x128 kernel, fix-up)
+//   plain orientation (a lane owns 4 consecutive rows of one column): load_col1 / finish4m / store4m.
 
 template <class T>
-__device__ __forceinline__ void store_half16(T* p, const float (&y)[16]) {   // 16 contiguous 16-bit values, 32-B aligned
+__device__ __forceinline__ void store_half16(T* p, const float (&y)[16]) {   // 16 contiguous 16-bit values, 16-B aligned
   alignas(16) T h[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) h[i] = (T)y[i];
@@ -36,33 +45,39 @@ __device__ __forceinline__ void store_half16(T* p, const float (&y)[16]) {   // 
   reinterpret_cast<uint4*>(p)[1] = reinterpret_cast<const uint4*>(h)[1];
 }
 
-// store16n(z, m, n0, v): C[m][n0 + 4*q + j] = v[q][j], q, j = 0..3  (256x256 kernel: one lane owns 16 columns)
+__device__ __forceinline__ float4 ldg4(const float* p, bool ok) {
+  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 template <class T> struct EpiBiasHalf {           // out16 = (acc + bias) [* scale for n < scale_cols]
-  static constexpr bool kWide = true;
+  static constexpr bool kWide = true, kResidual = false;
   T* out; const float* bias; int ldc; int scale_cols; float scale; int M, N;
-  __device__ __forceinline__ void store16n(int, int m, int n0, const f32x4 (&v)[4]) const {
+  __device__ __forceinline__ void load_cols(int n0, float4& b, float4&) const { b = ldg4(bias + n0, n0 < N); }
+  __device__ __forceinline__ float4 load_res(int, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 b, float4, float4) const {
+    if (m >= M || n0 >= N) return;
+    const float s = n0 < scale_cols ? scale : 1.0f;
+    *reinterpret_cast<Half4<T>*>(out + (size_t)m * ldc + n0) =
+        to_half4<T>((v[0] + b.x) * s, (v[1] + b.y) * s, (v[2] + b.z) * s, (v[3] + b.w) * s);
+  }
+  __device__ __forceinline__ void finish16n(int, int m, int n0, const f32x4 (&v)[4], const float4 (&b)[4]) const {
     if (m >= M || n0 >= N) return;
     if (n0 + 16 > N || (ldc & 7) || (scale_cols & 15)) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) store4n(0, m, n0 + 4 * q, v[q]);
+      for (int q = 0; q < 4; ++q) finish4n(0, m, n0 + 4 * q, v[q], b[q], b[q], b[q]);
       return;
     }
     const float s = n0 < scale_cols ? scale : 1.0f;
     float y[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 b = *reinterpret_cast<const float4*>(bias + n0 + 4 * q);
-      y[4 * q] = (v[q][0] + b.x) * s; y[4 * q + 1] = (v[q][1] + b.y) * s;
-      y[4 * q + 2] = (v[q][2] + b.z) * s; y[4 * q + 3] = (v[q][3] + b.w) * s;
+      y[4 * q] = (v[q][0] + b[q].x) * s; y[4 * q + 1] = (v[q][1] + b[q].y) * s;
+      y[4 * q + 2] = (v[q][2] + b[q].z) * s; y[4 * q + 3] = (v[q][3] + b[q].w) * s;
     }
     store_half16<T>(out + (size_t)m * ldc + n0, y);
   }
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
-    if (m >= M || n0 >= N) return;
-    float s = n0 < scale_cols ? scale : 1.0f;
-    const float4 b = *reinterpret_cast<const float4*>(bias + n0);
-    *reinterpret_cast<Half4<T>*>(out + (size_t)m * ldc + n0) =
-        to_half4<T>((v[0] + b.x) * s, (v[1] + b.y) * s, (v[2] + b.z) * s, (v[3] + b.w) * s);
+    float4 b, l; load_cols(n0, b, l); finish4n(0, m, n0, v, b, b, b);
   }
 };
 
@@ -82,75 +97,94 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 template <class T> struct EpiBiasGeluHalf {
-  static constexpr bool kWide = true;
+  static constexpr bool kWide = true, kResidual = false;
   T* out; const float* bias; int ldc; int M, N;
-  __device__ __forceinline__ void store16n(int, int m, int n0, const f32x4 (&v)[4]) const {
+  __device__ __forceinline__ void load_cols(int n0, float4& b, float4&) const { b = ldg4(bias + n0, n0 < N); }
+  __device__ __forceinline__ float4 load_res(int, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 b, float4, float4) const {
+    if (m >= M || n0 >= N) return;
+    *reinterpret_cast<Half4<T>*>(out + (size_t)m * ldc + n0) =
+        to_half4<T>(gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y), gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w));
+  }
+  __device__ __forceinline__ void finish16n(int, int m, int n0, const f32x4 (&v)[4], const float4 (&b)[4]) const {
     if (m >= M || n0 >= N) return;
     if (n0 + 16 > N || (ldc & 7)) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) store4n(0, m, n0 + 4 * q, v[q]);
+      for (int q = 0; q < 4; ++q) finish4n(0, m, n0 + 4 * q, v[q], b[q], b[q], b[q]);
       return;
     }
     float y[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 b = *reinterpret_cast<const float4*>(bias + n0 + 4 * q);
-      y[4 * q] = gelu_erf(v[q][0] + b.x); y[4 * q + 1] = gelu_erf(v[q][1] + b.y);
-      y[4 * q + 2] = gelu_erf(v[q][2] + b.z); y[4 * q + 3] = gelu_erf(v[q][3] + b.w);
+      y[4 * q] = gelu_erf(v[q][0] + b[q].x); y[4 * q + 1] = gelu_erf(v[q][1] + b[q].y);
+      y[4 * q + 2] = gelu_erf(v[q][2] + b[q].z); y[4 * q + 3] = gelu_erf(v[q][3] + b[q].w);
     }
     store_half16<T>(out + (size_t)m * ldc + n0, y);
   }
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
-    if (m >= M || n0 >= N) return;
-    const float4 b = *reinterpret_cast<const float4*>(bias + n0);
-    *reinterpret_cast<Half4<T>*>(out + (size_t)m * ldc + n0) =
-        to_half4<T>(gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y), gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w));
+    float4 b, l; load_cols(n0, b, l); finish4n(0, m, n0, v, b, b, b);
   }
 };
 
-struct EpiResidualF32 {
-  static constexpr bool kWide = false;                            // x += (acc + bias) * layerscale   (in place)
+struct EpiResidualF32 {                            // x += (acc + bias) * layerscale   (in place)
+  static constexpr bool kWide = false, kResidual = true;
   float* x; const float* bias; const float* ls; int ldc; int M, N;
-  __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
+  __device__ __forceinline__ void load_cols(int n0, float4& b, float4& l) const {
+    b = ldg4(bias + n0, n0 < N); l = ldg4(ls + n0, n0 < N);
+  }
+  __device__ __forceinline__ float4 load_res(int, int m, int n0) const {
+    return ldg4(x + (size_t)m * ldc + n0, m < M && n0 < N);
+  }
+  __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 b, float4 l, float4 r) const {
     if (m >= M || n0 >= N) return;
-    const float4 b = *reinterpret_cast<const float4*>(bias + n0);
-    const float4 l = *reinterpret_cast<const float4*>(ls + n0);
-    float4* p = reinterpret_cast<float4*>(x + (size_t)m * ldc + n0);
-    float4 r = *p;
     r.x += (v[0] + b.x) * l.x; r.y += (v[1] + b.y) * l.y;
     r.z += (v[2] + b.z) * l.z; r.w += (v[3] + b.w) * l.w;
-    *p = r;
+    *reinterpret_cast<float4*>(x + (size_t)m * ldc + n0) = r;
+  }
+  __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
+    float4 b, l; load_cols(n0, b, l); finish4n(0, m, n0, v, b, l, load_res(0, m, n0));
   }
 };
 
-struct EpiStoreF32 {
-  static constexpr bool kWide = false;                               // batched plain fp32 store (focal scores)
+struct EpiStoreF32 {                               // batched plain fp32 store (focal scores)
+  static constexpr bool kWide = false, kResidual = false;
   float* out; int ldc; long long strideC; int M, N;
-  __device__ __forceinline__ void store4n(int z, int m, int n0, f32x4 v) const {
+  __device__ __forceinline__ void load_cols(int, float4&, float4&) const {}
+  __device__ __forceinline__ float4 load_res(int, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ void finish4n(int z, int m, int n0, f32x4 v, float4, float4, float4) const {
     if (m >= M || n0 >= N) return;
     *reinterpret_cast<float4*>(out + z * strideC + (size_t)m * ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
   }
+  __device__ __forceinline__ void store4n(int z, int m, int n0, f32x4 v) const {
+    const float4 o = make_float4(0.f, 0.f, 0.f, 0.f); finish4n(z, m, n0, v, o, o, o);
+  }
 };
 
-struct EpiPatchEmbed {
-  static constexpr bool kWide = false;                             // token row b*T+1+p = acc + bias + pos[1+p]
+struct EpiPatchEmbed {                             // token row b*T+1+p = acc + bias + pos[1+p]
+  static constexpr bool kWide = false, kResidual = true;
   float* x; const float* bias; const float* pos; int D; int P; int M;   // P patches per image
-  __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
+  __device__ __forceinline__ void load_cols(int n0, float4& b, float4&) const { b = ldg4(bias + n0, n0 < D); }
+  __device__ __forceinline__ float4 load_res(int, int m, int n0) const {
+    const int p = m % P;
+    return ldg4(pos + (size_t)(1 + p) * D + n0, m < M && n0 < D);
+  }
+  __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 bi, float4, float4 po) const {
     if (m >= M || n0 >= D) return;
     const int b = m / P, p = m - b * P;
-    const float4 bi = *reinterpret_cast<const float4*>(bias + n0);
-    const float4 po = *reinterpret_cast<const float4*>(pos + (size_t)(1 + p) * D + n0);
     *reinterpret_cast<float4*>(x + ((size_t)b * (P + 1) + 1 + p) * D + n0) =
         make_float4(v[0] + bi.x + po.x, v[1] + bi.y + po.y, v[2] + bi.z + po.z, v[3] + bi.w + po.w);
+  }
+  __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
+    float4 b, l; load_cols(n0, b, l); finish4n(0, m, n0, v, b, b, load_res(0, m, n0));
   }
 };
 
 template <class T> struct EpiVT {                  // V^T[(b*H+h)*64 + d][t] (row length Tp), plain orientation
-  static constexpr bool kWide = false;
+  static constexpr bool kWide = false, kResidual = false;
   T* vt; const float* bias; int T_, Tp, M, N;
-  __device__ __forceinline__ void store4m(int, int m0, int n, f32x4 v) const {
+  __device__ __forceinline__ float load_col1(int n) const { return n < N ? bias[n] : 0.f; }
+  __device__ __forceinline__ void finish4m(int, int m0, int n, f32x4 v, float bi) const {
     if (m0 >= M || n >= N) return;
-    const float bi = bias[n];
     const int b = m0 / T_, t = m0 - b * T_;
     const int H = N >> 6;
     T* row = vt + ((size_t)(b * H + (n >> 6)) * 64 + (n & 63)) * Tp;
@@ -171,6 +205,7 @@ template <class T> struct EpiVT {                  // V^T[(b*H+h)*64 + d][t] (ro
       }
     }
   }
+  __device__ __forceinline__ void store4m(int, int m0, int n, f32x4 v) const { finish4m(0, m0, n, v, load_col1(n)); }
 };
 
 // ---- staging ---------------------------------------------------------------
@@ -255,13 +290,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmShape g, Epi epi) {
   }
 
   const int m_base = tm * BM + wm * 64, n_base = tn * BN + wn * 64;
+  if constexpr (SWAP) {
+    float4 cb[4], cl[4], xr[4][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) epi.load_cols(n_base + 16 * j + 4 * fq, cb[j], cl[j]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if constexpr (SWAP) epi.store4n(z, m_base + 16 * i + fr, n_base + 16 * j + 4 * fq, acc[i][j]);
-      else epi.store4m(z, m_base + 16 * i + 4 * fq, n_base + 16 * j + fr, acc[i][j]);
-    }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        xr[i][j] = Epi::kResidual ? epi.load_res(z, m_base + 16 * i + fr, n_base + 16 * j + 4 * fq) : cb[j];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        epi.finish4n(z, m_base + 16 * i + fr, n_base + 16 * j + 4 * fq, acc[i][j], cb[j], cl[j], xr[i][j]);
+  } else {
+    float cb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cb[j] = epi.load_col1(n_base + 16 * j + fr);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) epi.finish4m(z, m_base + 16 * i + 4 * fq, n_base + 16 * j + fr, acc[i][j], cb[j]);
+  }
 }
 
 constexpr int BM2 = 256, BN2 = 256;

@@ -218,17 +218,42 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
     const int tm = lt / sc.tiles_n, tn = lt - tm * sc.tiles_n;
     if (it.slice < 0) {
       const int m_base = tm * BM2 + wr * 128, n_base = tn * BN2 + wc * 64;
+      // all loads of the tile first, then the stores (see the note above the epilogues in gemm.hip)
+      if constexpr (WIDE) {
+        float4 cb[4], cl;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if constexpr (WIDE) {
-          epi.store16n(z, m_base + 16 * i + fr, n_base + 16 * fq, acc[i]);
-        } else {
+        for (int q = 0; q < 4; ++q) epi.load_cols(n_base + 16 * fq + 4 * q, cb[q], cl);
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            if constexpr (SWAP) epi.store4n(z, m_base + 16 * i + fr, n_base + 16 * jj + 4 * fq, acc[i][jj]);
-            else epi.store4m(z, m_base + 16 * i + 4 * fq, n_base + 16 * jj + fr, acc[i][jj]);
-          }
+        for (int i = 0; i < 8; ++i) epi.finish16n(z, m_base + 16 * i + fr, n_base + 16 * fq, acc[i], cb);
+      } else if constexpr (SWAP) {
+        float4 cb[4], cl[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) epi.load_cols(n_base + 16 * jj + 4 * fq, cb[jj], cl[jj]);
+#pragma unroll
+        for (int part = 0; part < 4; ++part) {        // 8 residual loads in flight per lane (register budget)
+          float4 xr[2][4];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+              xr[i][jj] = Epi::kResidual
+                  ? epi.load_res(z, m_base + 16 * (2 * part + i) + fr, n_base + 16 * jj + 4 * fq) : cb[jj];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+              epi.finish4n(z, m_base + 16 * (2 * part + i) + fr, n_base + 16 * jj + 4 * fq, acc[2 * part + i][jj],
+                           cb[jj], cl[jj], xr[i][jj]);
         }
+      } else {
+        float cb[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) cb[jj] = epi.load_col1(n_base + 16 * jj + fr);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            epi.finish4m(z, m_base + 16 * i + 4 * fq, n_base + 16 * jj + fr, acc[i][jj], cb[jj]);
       }
     } else {
       float4* out = reinterpret_cast<float4*>(sc.ws) +
