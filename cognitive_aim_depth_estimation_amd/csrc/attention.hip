@@ -20,6 +20,7 @@ constexpr int QB = 128;           // queries per block (4 waves x 32)
 constexpr int K_TILE = KV * 128;  // K tile: 64 keys x 64 d x 2 B, chunk-swizzled
 constexpr int V_ROW = 136;        // V^T tile row stride in bytes (64 keys + 8 B pad: conflict-free ds_read_b64)
 constexpr int V_TILE = 64 * V_ROW;
+constexpr float RESCALE_THR = 6.0f;   // log2 units
 
 template <class T>
 __global__ __launch_bounds__(256, 2) void mhsa_kernel(const T* __restrict__ qk, const T* __restrict__ vt,
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const T* __restrict__ qk, 
   f32x16 o[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = 0.f, l_run = 0.f;
 
   const int nt = (Tn + KV - 1) / KV;
   LOAD_TILE(0);
@@ -86,12 +87,14 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const T* __restrict__ qk, 
     const char* ks = smem + (t & 1) * K_TILE;
     const char* vs = smem + 2 * K_TILE + (t & 1) * V_TILE;
 
-    // S^T = K Q^T : s[kb][i] = S^T[key kb*32 + (i&3) + 8(i>>2) + 4hh][query ql]
+    // S^T = K Q^T - m_run : s[kb][i] = S^T[key kb*32 + (i&3) + 8(i>>2) + 4hh][query ql], already relative
+    // to the running maximum (the accumulator starts at -m_run, so no subtraction pass is needed)
     f32x16 s[2];
+    const float neg_m = -m_run;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+      for (int i = 0; i < 16; ++i) s[kb][i] = neg_m;
       const int r = kb * 32 + ql;
       const int sw = (r >> 1) & 7;
 #pragma unroll
@@ -109,31 +112,46 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const T* __restrict__ qk, 
           if (key >= Tn) s[kb][i] = -INFINITY;
         }
     }
-    // online softmax, per query column (lane-local + one half swap)
-    float mx = s[0][0];
+    // tile maximum per query column (lane-local + one half swap), relative to m_run
+    float mx;
+    {   // four independent chains (a single 31-deep dependent chain of v_max would serialise the wave)
+      float m4[4];
 #pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
+      for (int c = 0; c < 4; ++c) m4[c] = fmaxf(s[0][c], s[1][c]);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
+      for (int i = 4; i < 16; ++i) m4[i & 3] = fmaxf(m4[i & 3], fmaxf(s[0][i], s[1][i]));
+      mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    }
     {
       const unsigned u = __float_as_uint(mx);
       auto sw2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
       mx = fmaxf(__uint_as_float(sw2[0]), __uint_as_float(sw2[1]));
     }
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float lsum = 0.f;
+    // Deferred rescale: the running maximum only moves when some query of the wave sees a score more
+    // than RESCALE_THR (log2 units) above it; until then exp2 runs on the accumulator as it is and the
+    // probabilities are bounded by 2^RESCALE_THR, exact in 16-bit floating point.  The first tile always
+    // sets the maximum (m_run starts at 0 there).
+    const bool rescale = (t == 0) || !__all(mx <= RESCALE_THR);
+    if (rescale) {
+      const float d = (t == 0) ? mx : fmaxf(mx, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-d);
+      m_run += d;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        o[0][i] *= alpha; o[1][i] *= alpha;
+        s[0][i] -= d; s[1][i] -= d;
+      }
+    }
+    float l4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        s[kb][i] = __builtin_amdgcn_exp2f(s[kb][i] - m_new);
-        lsum += s[kb][i];
+        s[kb][i] = __builtin_amdgcn_exp2f(s[kb][i]);
+        l4[i & 3] += s[kb][i];
       }
-    l_run = l_run * alpha + lsum;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+    l_run += (l4[0] + l4[1]) + (l4[2] + l4[3]);
 
     // O^T += V^T P^T : A = V^T fragment (rows = d), B = P^T fragment (the S^T registers)
 #pragma unroll

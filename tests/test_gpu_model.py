@@ -157,3 +157,34 @@ def test_batch_independence_and_determinism():
     for sl in (slice(0, 2), slice(2, 5)):
         ds, cs = model(x[sl], {k: v[sl] for k, v in exif.items()})
         assert torch.equal(ds, d[sl]) and torch.equal(cs, c[sl])
+
+
+@pytest.mark.parametrize("size,B", [((266, 266), 1), ((224, 448), 3), ((98, 70), 33)])
+def test_odd_shapes_vs_oracle(size, B):
+    """Odd grids (19x19), non-square images (non-square patch count -> 1-D position table and centre
+    bias, bicubic position-embedding resampling to a rectangular grid) and a ragged batch."""
+    model, sd = synth_model_and_sd(2, 4, seed=21, dtype="fp16")
+    torch.manual_seed(B)
+    x = torch.randn(B, 3, *size)
+    exif = default_exif(B)
+    d_ref, c_ref, a_ref = O.forward(sd, x, exif, return_attention=True)
+    d, c, a = model(x.cuda(), {k: v.cuda() for k, v in exif.items()}, return_attention=True)
+    e = dict(depth=rel_err(d, d_ref), conf=rel_err(c, c_ref), attn=rel_err(a, a_ref))
+    report(test="odd_shapes", size=list(size), B=B, **e)
+    assert e["depth"] <= DEPTH_TOL and e["conf"] <= DEPTH_TOL and e["attn"] <= 3e-2, e
+
+
+def test_high_resolution_eight_iterations():
+    """BASELINE config 5 geometry: 1036x1036 input (74x74 = 5476 patches), 8 focal iterations, fp16
+    operands; 2-layer backbone so that the CPU oracle finishes in seconds."""
+    model, sd = synth_model_and_sd(2, 37, iters=8, seed=5, dtype="fp16")
+    torch.manual_seed(8)
+    x = torch.randn(1, 3, 1036, 1036)
+    exif = default_exif(1)
+    d_ref, c_ref, a_ref = O.forward(sd, x, exif, return_attention=True)
+    d, c, a = model(x.cuda(), {k: v.cuda() for k, v in exif.items()}, return_attention=True)
+    e = dict(depth=rel_err(d, d_ref), conf=rel_err(c, c_ref), attn=rel_err(a, a_ref))
+    report(test="config5_1036_I8", **e)
+    assert a.shape == (1, 5476)
+    assert e["depth"] <= DEPTH_TOL and e["conf"] <= DEPTH_TOL and e["attn"] <= 3e-2, e
+    model.synchronize()
