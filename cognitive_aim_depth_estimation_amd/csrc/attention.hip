@@ -31,8 +31,17 @@ __global__ __launch_bounds__(256, 2) void mhsa_kernel(const T* __restrict__ qk, 
   typedef T v4 __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, hh = lane >> 5;
-  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-  const int q0 = blockIdx.x * QB + wave * 32;
+  // Workgroups are dealt round-robin over the 8 XCDs (private L2 each): remap the linear id so that the
+  // query blocks of one (image, head) -- which all stream the same K/V -- are neighbours on ONE XCD.
+  const int nqb = (Tn + QB - 1) / QB;
+  int lid;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int bh = lid / nqb, b = bh / H, h = bh - b * H;
+  const int q0 = (lid - bh * nqb) * QB + wave * 32;
   const size_t row0 = (size_t)b * Tn;
 
   // Q fragments: B operand, lane (q = ql, half hh) holds Q[q][16 s + 8 hh .. +7]
@@ -208,7 +217,7 @@ int cogaim_mhsa_fwd(const void* qk, const void* vt, void* ctx, int B, int T, int
                     void* stream) {
   if (B <= 0 || T <= 0 || H <= 0 || (Tp & 63) || Tp < T || (ldqk & 7)) return COGAIM_EINVAL;
   const int D = 64 * H;
-  dim3 grid((T + QB - 1) / QB, B * H);
+  dim3 grid(((T + QB - 1) / QB) * B * H);
   if (dtype == 0)
     hipLaunchKernelGGL(mhsa_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)qk,
                        (const __bf16*)vt, (__bf16*)ctx, T, H, Tp, ldqk, D);
