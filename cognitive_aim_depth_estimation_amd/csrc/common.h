@@ -74,5 +74,25 @@ __device__ __forceinline__ float block_max_256(float v, float* red) {
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// 16-byte-per-lane DMA from global memory straight into LDS (no VGPR round trip): lane i's 16 bytes
+// land at lds_wave_base + 16 i, the source address is free per lane.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// The same DMA through a buffer resource (buffer_load_dwordx4 ... lds): byte offsets instead of
+// pointers, reads past num_bytes return zero instead of faulting, and -- unlike the global_ form, which
+// the compiler treats as a flat access and answers with lgkmcnt(0) before every later LDS read -- it
+// leaves the compiler's LDS wait counting exact.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned num_bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)num_bytes, 0x00020000);
+}
+__device__ __forceinline__ void bufload_lds16(__amdgpu_buffer_rsrc_t rsrc, int lane_byte_offset, int wave_byte_offset,
+                                              void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
+                                           lane_byte_offset, wave_byte_offset, 0, 0);
+}
+
 static inline int hip_rc(hipError_t e) { return e == hipSuccess ? COGAIM_OK : -1000 - (int)e; }
 #define COGAIM_LAUNCH_CHECK() hip_rc(hipGetLastError())

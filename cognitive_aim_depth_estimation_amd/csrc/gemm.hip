@@ -85,15 +85,18 @@ template <class T> struct EpiBiasHalf {           // out16 = (acc + bias) [* sca
 // rational form of erfc (|abs error| <= 1.5e-7, far below the 16-bit rounding of the output);
 // the negative branch uses erfc directly, so there is no cancellation in the tail.
 __device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-  float p = 1.061405429f;
-  p = p * t - 1.453152027f;
-  p = p * t + 1.421413741f;
-  p = p * t - 0.284496736f;
-  p = p * t + 0.254829592f;
-  const float erfc_half = 0.5f * p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
-  return x * (x < 0.f ? erfc_half : 1.0f - erfc_half);
+  // u = |x| sqrt(log2(e) / 2), so that exp(-x^2 / 2) = exp2(-u^2); the 0.5 of Phi is folded into the
+  // coefficients; gelu(x) = max(x, 0) - |x| * erfc(|x| / sqrt 2) / 2 covers both signs without a select.
+  const float ax = fabsf(x);
+  const float u = ax * 0.84932180028801904272f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.27273748087922245f, u, 1.0f));
+  float p = 0.5f * 1.061405429f;
+  p = __builtin_fmaf(p, t, 0.5f * -1.453152027f);
+  p = __builtin_fmaf(p, t, 0.5f * 1.421413741f);
+  p = __builtin_fmaf(p, t, 0.5f * -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.5f * 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-(u * u));
+  return __builtin_fmaf(-ax, (p * t) * e, fmaxf(x, 0.f));
 }
 
 template <class T> struct EpiBiasGeluHalf {
@@ -208,12 +211,6 @@ template <class T> struct EpiVT {                  // V^T[(b*H+h)*64 + d][t] (ro
   __device__ __forceinline__ void store4m(int, int m0, int n, f32x4 v) const { finish4m(0, m0, n, v, load_col1(n)); }
 };
 
-// ---- staging ---------------------------------------------------------------
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
 // bijective XCD-aware remap: blocks that share an XCD (bid % 8) get a contiguous tile range
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -319,6 +316,8 @@ constexpr int BM2 = 256, BN2 = 256;
 constexpr int OP_BYTES = 256 * BK * 2;        // 32 KiB per operand per stage
 constexpr int STAGE_BYTES = 2 * OP_BYTES;     // 64 KiB
 
+int g_gemm_band = -1;  // tile numbering of the persistent kernel: -1 = chosen per shape; tools/ may force a value
+
 #include "gemm_persistent.h"
 
 int g_gemm_diag = 0;   // timing-only diagnostic variants (wrong results); never set outside tools/
@@ -418,6 +417,7 @@ int cogaim_gemm_vt(const void* A, const void* W, const float* bias, void* vt, in
 // Tuning knob: 0 = 128x128 kernel for every problem; 1 = 256x256 kernel, one tile per workgroup;
 // 2 (default) = persistent 256x256 kernel.  1 and 2 apply to large problems only.
 int cogaim_set_gemm_algo(int algo) {
+  if (algo >= 200) { g_gemm_band = algo == 299 ? -1 : algo - 200; return COGAIM_OK; }   // tools/gemm_bench.py only
   if (algo >= 100) { g_gemm_diag = 1; g_gemm_algo = algo - 100; return COGAIM_OK; }   // tools/gemm_bench.py only
   if (algo < 0 || algo > 2) return COGAIM_EINVAL;
   g_gemm_algo = algo;

@@ -35,7 +35,11 @@ __device__ __forceinline__ int swz_a(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int swz_w(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
 
 struct PersistSched {
+  int tiles_m;        // row tiles of one problem
   int tiles_n;        // column tiles of one problem
+  int band;           // tiles are numbered band by band (band = `band` row tiles), rows fastest inside a band
+                      // when band > 1, so that the 32 consecutive tiles an XCD works on at a time form a
+                      // band x (32 / band) block: fewer distinct A / W panels per L2 than a 1 x N strip
   int tiles_per_z;    // tiles of one problem (batched GEMM: tile index = z * tiles_per_z + local tile)
   int n_full;         // tiles [0, n_full) are processed whole by workgroups [0, nblk_full), n_full % nblk_full == 0
   int nblk_full;
@@ -44,6 +48,14 @@ struct PersistSched {
   int slice_block0;   // ... handled by workgroups [slice_block0, slice_block0 + n_split*slices), after their whole tiles
   float* ws;          // [split tile][slice][32 fragments][512 threads] float4 (slices >= 2 only)
 };
+
+__device__ __forceinline__ void tile_coords(const PersistSched& sc, int lt, int& tm, int& tn) {
+  if (sc.band <= 1) { tm = lt / sc.tiles_n; tn = lt - tm * sc.tiles_n; return; }
+  const int per_band = sc.band * sc.tiles_n;
+  const int b = lt / per_band, r = lt - b * per_band;
+  const int m0 = b * sc.band, h = min(sc.band, sc.tiles_m - m0);
+  tn = r / h; tm = m0 + (r - tn * h);
+}
 
 template <class T, class Epi, bool SWAP, int DIAG>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, PersistSched sc) {
@@ -97,7 +109,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
   auto dma_set_item = [&](int j) {
     const Item it = item_at(j);
     const int z = it.tile / sc.tiles_per_z, lt = it.tile - z * sc.tiles_per_z;
-    const int tm = lt / sc.tiles_n, tn = lt - tm * sc.tiles_n;
+    int tm, tn; tile_coords(sc, lt, tm, tn);
     const T* A = A0 + z * g.strideA;
     const T* W = W0 + z * g.strideW;
     d_kt = it.kt0; d_kt1 = it.kt1;
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
     }
 
     const int z = it.tile / sc.tiles_per_z, lt = it.tile - z * sc.tiles_per_z;
-    const int tm = lt / sc.tiles_n, tn = lt - tm * sc.tiles_n;
+    int tm, tn; tile_coords(sc, lt, tm, tn);
     if (it.slice < 0) {
       const int m_base = tm * BM2 + wr * 128, n_base = tn * BN2 + wc * 64;
       // all loads of the tile first, then the stores (see the note above the epilogues in gemm.hip)
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(512) void gemm256p_fixup_kernel(Epi epi, PersistSch
   const int st = blockIdx.x, i = blockIdx.y >> 2, jj = blockIdx.y & 3;
   const int tile = sc.n_full + st;
   const int z = tile / sc.tiles_per_z, lt = tile - z * sc.tiles_per_z;
-  const int tm = lt / sc.tiles_n, tn = lt - tm * sc.tiles_n;
+  int tm, tn; tile_coords(sc, lt, tm, tn);
   const float4* in = reinterpret_cast<const float4*>(sc.ws) + ((size_t)st * sc.slices * 32 + blockIdx.y) * 512 + tid;
   float4 a = in[0];
   for (int s = 1; s < sc.slices; ++s) {
@@ -309,7 +321,9 @@ int launch_persistent(const GemmShape& g, const Epi& epi, int batch, hipStream_t
   const int tm2 = (g.M + BM2 - 1) / BM2, tn2 = (g.N + BN2 - 1) / BN2;
   const int tiles_per_z = tm2 * tn2, tiles = tiles_per_z * batch, nk = g.K / BK;
   const int lanes = tiles < CUS ? tiles : CUS;                 // concurrent workgroups
-  PersistSched sc{tn2, tiles_per_z, (tiles / lanes) * lanes, 0, 0, 1, 0, (float*)workspace};
+  // 8 x 4 blocks per XCD when the column tiles divide evenly into fours and there is more W than one L2 keeps
+  const int band = (g_gemm_band >= 0) ? g_gemm_band : ((tn2 % 4 == 0 && tn2 >= 8) ? 8 : 1);
+  PersistSched sc{tm2, tn2, band, tiles_per_z, (tiles / lanes) * lanes, 0, 0, 1, 0, (float*)workspace};
   const int rem = tiles - sc.n_full;
   if (rem > 0) {
     sc.n_split = rem;

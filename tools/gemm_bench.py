@@ -27,6 +27,9 @@ shapes = {
     "fc2   [M,768,3072]": ("res", 768, 3072),
     "vt    [M,768,768]": ("vt", 768, 768),
 }
+if os.environ.get("EXTRA"):      # same shape, different epilogue: isolates the epilogue cost
+    shapes["fc1b  [M,3072,768]"] = ("bias", 3072, 768)
+    shapes["qkg   [M,1536,768]"] = ("gelu", 1536, 768)
 WSB = torch.empty(call("cogaim_gemm_workspace_bytes"), device=dev, dtype=torch.uint8)
 USE_WS = os.environ.get("NO_WS") is None
 wsp = (WSB.data_ptr(), WSB.numel()) if USE_WS else (None, 0)
