@@ -59,6 +59,28 @@ def gemm_flops(name, args):
     return 2.0 * M * N * K, (M, N, K)
 
 
+# C-ABI entry point -> kernel name in the committed rocprofv3 PMC summaries (profiles/*_hbm_traffic.json)
+_PROFILE_KERNEL = {"cogaim_gemm_bias_gelu_half": "gemm256p<EpiBiasGeluHalf>", "cogaim_gemm_bias_half": "gemm256p<EpiBiasHalf>",
+                   "cogaim_gemm_residual_f32": "gemm256p<EpiResidualF32>", "cogaim_gemm_vt": "gemm256p<EpiVT>",
+                   "cogaim_mhsa_fwd": "mhsa", "cogaim_layernorm": "layernorm"}
+
+
+def measured_traffic(entry):
+    """HBM bytes per launch of the dominant kernel, from the newest PMC pass kept under profiles/
+    (FETCH_SIZE / WRITE_SIZE cannot be read from inside this process; the pass is a separate rocprofv3 run
+    of this same script, summarised by tools/summarize_profile.py)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    key = _PROFILE_KERNEL.get(entry)
+    if not files or key is None:
+        return None, None
+    with open(files[-1]) as f:
+        k = json.load(f)["kernels"].get(key)
+    if k is None:
+        return None, None
+    return int(k["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,9 +196,10 @@ def main():
         (dname, dshape), (dms, dcnt, dfl) = next((kv for kv in top if kv[1][2]), top[0])
         avg_ms = dms / dcnt
         achieved = dfl / (avg_ms * 1e-3) / 1e12
+        traffic, traffic_src = measured_traffic(dname)
         out["roofline"] = {"bound": "mfma", "kernel": f"{dname}{list(dshape)}", "avg_launch_ms": round(avg_ms, 4),
                            "achieved": round(achieved, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None}
+                           "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cogaim_oracle as O

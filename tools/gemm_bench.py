@@ -17,7 +17,9 @@ torch.manual_seed(0)
 
 
 def mk(m, k):
-    return (torch.randn(m, k, device=dev) * 0.5).to(tdt)
+    if os.environ.get("ZERO"):       # all-zero operands: same instruction stream at the lowest switching power
+        return torch.zeros(m, k, device=dev, dtype=tdt)
+    return (torch.randn(m, k, device=dev) * float(os.environ.get("SCALE", "0.5"))).to(tdt)
 
 
 shapes = {
