@@ -18,6 +18,7 @@ P, I, F, LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 # name -> argument types (all return int); mirrors include/cogaim.h
 SIGNATURES = {
     "cogaim_version": [],
+    "cogaim_allgather_f32": [P, P, LL, P, P],
     "cogaim_gemm_workspace_bytes": [],
     "cogaim_set_gemm_algo": [I],
     "cogaim_im2col": [P, P, I, I, I, I, I, I, P],

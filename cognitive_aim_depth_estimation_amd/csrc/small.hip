@@ -3,6 +3,7 @@
 // :482-519 EXIF prior, :908-941 fusion / decision / confidence heads).
 // Batch-many-rows x few-hundred-columns: GEMV class, one wave per output.
 #include "common.h"
+#include <dlfcn.h>
 
 namespace {
 
@@ -109,5 +110,27 @@ int cogaim_heads(const float* fused, int K, const float* wd, const float* bd, co
 }
 
 int cogaim_version() { return 1; }
+
+// All-gather of `count` floats per rank over RCCL on `stream` (the per-image (depth, confidence) rows of an
+// image-sharded batch).  The collective library is looked up at run time -- first a copy this process has
+// already loaded (a host framework's own RCCL, so that `comm` belongs to the library that is called), else
+// the system librccl -- which keeps libcogaim.so free of a link-time dependency for single-GPU users.
+int cogaim_allgather_f32(const float* send, float* recv, long long count, void* comm, void* stream) {
+  typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+  static allgather_fn fn = nullptr;
+  static bool looked_up = false;
+  if (!looked_up) {
+    looked_up = true;
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW);
+    if (h) fn = (allgather_fn)dlsym(h, "ncclAllGather");
+  }
+  if (!fn) return -38;                                    // ENOSYS: no RCCL in this process or on this host
+  if (!send || !recv || count < 0 || !comm) return COGAIM_EINVAL;
+  const int rc = fn(send, recv, (size_t)count, /* ncclFloat32 */ 7, comm, (hipStream_t)stream);
+  return rc == 0 ? COGAIM_OK : -2000 - rc;
+}
 
 }  // extern "C"

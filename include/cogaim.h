@@ -27,6 +27,13 @@ extern "C" {
 
 int cogaim_version(void);
 
+/* Multi-GPU: the only data-path exchange of the image-sharded forward (one process per GPU, weights
+ * replicated) -- every rank contributes `count` floats (its [B_local, 2] depth/confidence rows) and
+ * receives world_size * count.  Wraps ncclAllGather of the RCCL copy already loaded in the process (or
+ * the system one); `comm` is that library's ncclComm_t.  The reference has no multi-GPU path
+ * (demo.py:406-432 is a sequential single-device loop).  Returns -38 when no RCCL can be found. */
+int cogaim_allgather_f32(const float* send, float* recv, long long count, void* comm, void* stream);
+
 /* The GEMM entry points take an optional `workspace` (device memory, `workspace_bytes` long;
  * NULL/0 allowed).  With at least cogaim_gemm_workspace_bytes() bytes they split the tiles of
  * a partial last round along K over the idle CUs (fp32 partials, summed in fixed order: results

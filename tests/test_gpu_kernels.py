@@ -252,3 +252,38 @@ def test_large_gemm_kernels_agree(dtype, M, N, K):
         call("cogaim_gemm_vt", ptr(A), ptr(W), ptr(bias), ptr(vt), B, T, N, K, K, K, Tp, di, *WS(), stream_ptr())
         refv = (A[: B * T].float() @ W.float().t() + bias).view(B, T, N // 64, 64).permute(0, 2, 3, 1)
         assert torch.allclose(vt.view(B, N // 64, 64, Tp)[..., :T].float(), refv, rtol=tol, atol=tol)
+
+
+def test_allgather_f32_single_rank():
+    """cogaim_allgather_f32 over a one-rank RCCL communicator built through the RCCL copy torch ships
+    (the same library the entry point finds already loaded): the gather of one rank is a copy."""
+    import ctypes
+    import glob
+    import os
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["librccl.so.1"]
+    rccl = None
+    for c in cands:
+        try:
+            rccl = ctypes.CDLL(c, mode=ctypes.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("no RCCL library on this host")
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid, comm = UniqueId(), ctypes.c_void_p()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        send = rnd(64, 2)
+        recv = torch.zeros_like(send)
+        call("cogaim_allgather_f32", ptr(send), ptr(recv), send.numel(), comm.value, stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)

@@ -10,6 +10,7 @@ import collections
 import csv
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,6 +22,16 @@ def short(name):
         if key in name:
             epi = [e for e in ("EpiBiasGeluHalf", "EpiBiasHalf", "EpiResidualF32", "EpiStoreF32", "EpiPatchEmbed", "EpiVT") if e in name]
             return tag + ("<" + epi[0] + ">" if epi else "")
+    m = re.search(r"_GLOBAL__N_1(\d+)", name)                 # mangled: _ZN12_GLOBAL__N_1<len><identifier>...
+    if m:
+        n0 = m.end()
+        return name[n0:n0 + int(m.group(1))]
+    m = re.search(r"\(anonymous namespace\)::(\w+)", name)  # demangled
+    if m:
+        return m.group(1)
+    m = re.search(r"at::native::(\w+)", name)
+    if m:
+        return "at::native::" + m.group(1)
     return name.split("(")[0][-60:]
 
 
