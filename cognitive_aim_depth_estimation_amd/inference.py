@@ -74,6 +74,54 @@ def preprocess_image(image, size: Tuple[int, int]) -> torch.Tensor:
     return (arr - mean) / std
 
 
+class DevicePreprocessor:
+    """``preprocess_image`` on the GPU: the decoded RGB bytes go to the device as they are (3 B per source
+    pixel) and one C-ABI call resizes, scales and normalises them into a slot of the batch tensor,
+    bit-identical to the host path (Pillow's integer bilinear resampler, reference demo.py:162-166).
+    Per-axis weight tables are cached per (source length, output length)."""
+
+    def __init__(self, size: Tuple[int, int], device):
+        from . import tables
+        self.size = (int(size[0]), int(size[1]))
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DevicePreprocessor needs the GPU; use preprocess_image on the host")
+        self._tables = tables
+        self._axis = {}
+        self._lut = tables.normalize_lut(IMAGENET_MEAN, IMAGENET_STD).contiguous().to(self.device)
+        self._tmp = None
+
+    def _axis_tables(self, n_in: int, n_out: int):
+        key = (n_in, n_out)
+        if key not in self._axis:
+            bounds, coefs = self._tables.resample_coefficients(n_in, n_out)
+            self._axis[key] = (torch.from_numpy(bounds).to(self.device), torch.from_numpy(coefs).to(self.device),
+                               int(coefs.shape[1]))
+        return self._axis[key]
+
+    def __call__(self, image, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """image: PIL image (any mode) or uint8 array [h, w, 3].  out: optional fp32 [3, H, W] device view."""
+        from ._lib import call, ptr, stream_ptr
+        arr = np.array(image.convert("RGB") if hasattr(image, "convert") else image, dtype=np.uint8)
+        if arr.ndim != 3 or arr.shape[2] != 3:
+            raise ValueError(f"expected an RGB image, got array of shape {arr.shape}")
+        h, w = int(arr.shape[0]), int(arr.shape[1])
+        H, W = self.size
+        src = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+        xb, xc, xk = self._axis_tables(w, W)
+        yb, yc, yk = self._axis_tables(h, H)
+        need = h * W * 3
+        if self._tmp is None or self._tmp.numel() < need:
+            self._tmp = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if out is None:
+            out = torch.empty(3, H, W, dtype=torch.float32, device=self.device)
+        if out.shape != (3, H, W) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != src.device:
+            raise ValueError("out must be a contiguous fp32 [3, H, W] tensor on the preprocessing device")
+        call("cogaim_preprocess_rgb8", ptr(src), h, w, w * 3, ptr(xb), ptr(xc), xk, ptr(yb), ptr(yc), yk,
+             ptr(self._tmp), ptr(self._lut), ptr(out), H, W, stream_ptr())
+        return out
+
+
 def extract_exif(image_path: str) -> Optional[Dict]:
     """reference demo.py:170-255: FocalLength / FNumber / ExposureTime / ISO with range checks, Make / Model."""
     try:
@@ -208,6 +256,7 @@ class CognitiveAimInference:
         self.camera_to_id = {"unknown": 0}
         self.batch_size = int(batch_size)
         self.render = render
+        self.preprocess = DevicePreprocessor(self.image_size, self.device)
 
     def _load_checkpoint(self, checkpoint_path: str):
         """Tolerant loader of reference demo.py:89-150: accepts {'model_state_dict'|'main_model'|raw},
@@ -251,7 +300,7 @@ class CognitiveAimInference:
         for i in range(lo, hi):
             try:
                 image = Image.open(paths[i]).convert("RGB")
-                loaded.append((i, preprocess_image(image, self.image_size), extract_exif(paths[i]), image.size))
+                loaded.append((i, self.preprocess(image), extract_exif(paths[i]), image.size))
             except Exception as e:
                 if not tolerate_errors:
                     raise ValueError(f"Cannot load image {paths[i]}: {e}")
@@ -263,7 +312,7 @@ class CognitiveAimInference:
         for instruction, items in groups.items():
             for s in range(0, len(items), self.batch_size):
                 chunk = items[s: s + self.batch_size]
-                x = torch.stack([c[1] for c in chunk]).to(self.device, non_blocking=True)
+                x = torch.stack([c[1] for c in chunk])
                 exif = {k: v.to(self.device) for k, v in exif_rows([c[2] for c in chunk], self.camera_to_id).items()}
                 if hasattr(self.model, "_last_attention_weights"):
                     delattr(self.model, "_last_attention_weights")          # reference demo.py:334-335

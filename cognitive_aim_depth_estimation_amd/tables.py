@@ -114,3 +114,42 @@ def interpolate_position_embeddings(pos: torch.Tensor, gh: int, gw: int) -> torc
     grid = F.interpolate(grid, size=(gh, gw), mode="bicubic", align_corners=False)
     grid = grid.permute(0, 2, 3, 1).reshape(gh * gw, d)
     return torch.cat((pos[0, :1], grid), dim=0).contiguous()
+
+
+# --------------------------------------------------------------------------
+# image preprocessing tables (reference demo.py:162-166: Resize -> ToTensor -> Normalize)
+# --------------------------------------------------------------------------
+RESAMPLE_PRECISION_BITS = 22      # Pillow's 8-bit resampler: 32 - 8 - 2 fractional bits per weight
+
+
+def resample_coefficients(in_size: int, out_size: int):
+    """Per output index of one image axis: (first source index, tap count) and the integer bilinear weights
+    Pillow's ``Image.resize(..., BILINEAR)`` uses (triangle filter whose support grows with the shrink factor,
+    weights normalised in double precision and rounded to 22 fractional bits).  Returns
+    ``bounds int32 [out_size, 2]`` and ``coefs int32 [out_size, ksize]`` (unused taps are zero)."""
+    import numpy as np
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    center = (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)              # C (int) cast: truncation
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    taps = np.arange(ksize, dtype=np.float64)[None, :]
+    arg = np.abs((taps + xmin[:, None] - center[:, None] + 0.5) * (1.0 / filterscale))
+    w = np.where(arg < 1.0, 1.0 - arg, 0.0)
+    w = np.where(taps < xmax[:, None], w, 0.0)
+    # the reference sums the weights left to right; cumulative summation keeps that order exactly
+    ww = np.cumsum(w, axis=1)[:, -1:]
+    w = np.where(ww != 0.0, w / np.where(ww != 0.0, ww, 1.0), w)
+    q = w * float(1 << RESAMPLE_PRECISION_BITS)
+    coefs = np.where(w < 0, (-0.5 + q), (0.5 + q)).astype(np.int64).astype(np.int32)   # truncation, as (int)
+    bounds = np.stack([xmin, xmax], axis=1).astype(np.int32)
+    return bounds, coefs
+
+
+def normalize_lut(mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)) -> torch.Tensor:
+    """float32 [3, 256]: ToTensor's v / 255 followed by Normalize's (x - mean) / std for every byte value,
+    evaluated with the same float32 operations as the reference's transforms."""
+    v = torch.arange(256, dtype=torch.float32).div(255)
+    return torch.stack([v.sub(torch.tensor(mean[c])).div(torch.tensor(std[c])) for c in range(3)])
