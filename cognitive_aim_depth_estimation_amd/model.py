@@ -231,6 +231,8 @@ class CognitiveAimModel(nn.Module):
         self.compute_dtype = str(config.get("compute_dtype", os.environ.get("COGAIM_DTYPE", "fp16")))
         if self.compute_dtype not in _DTYPES:
             raise ValueError(f"compute_dtype must be one of {sorted(_DTYPES)}")
+        # replay the per-shape launch sequence as one HIP graph after its first (eager) run
+        self.use_graph = bool(config.get("use_hip_graph", os.environ.get("COGAIM_GRAPH", "1") != "0"))
 
         spec = state_spec(self.feature_dim, self.num_layers, self.patch_size, self.native_grid,
                           self.num_iterations, num_cameras, self.use_ambient, self.use_focal,
@@ -313,6 +315,8 @@ class CognitiveAimModel(nn.Module):
         pk["f32"] = {k: v.float().contiguous() for k, v in sd.items()
                      if v.dtype.is_floating_point and not k.startswith("backbone.encoder")}
         self._packed, self._packed_sig = pk, sig
+        for ws in self._ws.values():          # captured graphs hold the old weight pointers
+            ws.pop("graphs", None)
         self._tab.clear()
         return pk
 
@@ -375,7 +379,8 @@ class CognitiveAimModel(nn.Module):
             "feats": torch.empty(B, 64 * max(1, self.num_iterations), **f32),
             "exf": torch.empty(B, 128, **f32), "cont": torch.empty(B, 3, **f32),
             "cat": torch.zeros(B, 192, **f32), "fused": torch.empty(B, 192, **f32),
-            "guided": torch.empty(B, N, **f32),
+            "guided": torch.empty(B, N, **f32), "out": torch.empty(2, B, **f32),
+            "pw": torch.empty(64, D, **f32), "pb": torch.empty(64, **f32),
         }
         self._ws[key] = ws
         return ws
@@ -388,18 +393,22 @@ class CognitiveAimModel(nn.Module):
         O, K = W.shape
         call("cogaim_linear_f32", x, ldx, ptr(W), ptr(bias), ptr(bias_scale), out, ldo, B, O, K, act, stream_ptr())
 
-    def _backbone(self, images: torch.Tensor, ws: dict):
-        """DINOv2 forward (hf:451-477) -> ws['tokens'] fp32 [B*T, D] (final LayerNorm applied)."""
+    def _backbone(self, images: Optional[torch.Tensor], shape: Tuple[int, int, int], ws: dict):
+        """DINOv2 forward (hf:451-477) -> ws['tokens'] fp32 [B*T, D] (final LayerNorm applied).
+        Two parts: with ``images`` only the patch gather into the workspace runs; with ``images=None`` the
+        rest (patch embedding GEMM ... final LayerNorm), which touches workspace buffers only."""
         pk, st = self._packed, stream_ptr()
         dt, _ = _DTYPES[self.compute_dtype]
-        B, _, Hi, Wi = images.shape
+        B, Hi, Wi = shape
         p, D, H = self.patch_size, self.feature_dim, self.num_heads
         gh, gw = Hi // p, Wi // p
         N, T, M, Tp = ws["N"], ws["T"], ws["M"], ws["Tp"]
         pos = self._table("pos", gh, gw)
         x, h, qk, vt, ctx, big = (ws[k].data_ptr() for k in ("x", "h", "qk", "vt", "ctx", "big"))
         gw, gwb = ws["gemm_ws"].data_ptr(), ws["gemm_ws"].numel()
-        call("cogaim_im2col", images.data_ptr(), big, B, Hi, Wi, p, pk["pe_kp"], dt, st)
+        if images is not None:                 # eager: reads the caller's tensor (everything after it is static)
+            call("cogaim_im2col", images.data_ptr(), big, B, Hi, Wi, p, pk["pe_kp"], dt, st)
+            return
         call("cogaim_cls_row", ptr(pk["cls"]), ptr(pos), x, B, T, D, st)
         call("cogaim_gemm_patch_embed", big, ptr(pk["pe_w"]), ptr(pk["pe_b"]), ptr(pos), x, B, N, D, pk["pe_kp"], dt, gw, gwb, st)
         qscale = 64 ** -0.5 * LOG2E
@@ -508,12 +517,16 @@ class CognitiveAimModel(nn.Module):
         idx = vec("camera_idx", torch.int64)
         return idx, vec("focal_length", torch.float32), vec("aperture", torch.float32), vec("iso", torch.float32)
 
-    def _exif(self, exif_in, ws, B, col):
+    def _exif_prep(self, exif_in, ws, B):
+        """Embedding gather + [focal, aperture, log(iso+1)] (src/model.py:491-512): the only EXIF step that
+        reads the caller's tensors."""
         idx, fl, ap, iso = exif_in
         emb = self._packed["f32"]["exif_prior.camera_embedding.weight"]
         # an out-of-range camera index is reported through flag slot 15 (examined with the other flags)
         call("cogaim_exif_prep", ptr(idx), ptr(fl), ptr(ap), ptr(iso), ptr(emb), emb.shape[0], 64, ptr(ws["exf"]), 128,
              ptr(ws["cont"]), B, ws["flags"].data_ptr() + 15 * 4, stream_ptr())
+
+    def _exif(self, ws, B, col):
         self._linear(ptr(ws["cont"]), 3, "exif_prior.exif_encoder.0", ptr(ws["t64"]), 64, B, act=1)
         self._linear(ptr(ws["t64"]), 64, "exif_prior.exif_encoder.2", ws["exf"].data_ptr() + 64 * 4, 128, B)
         self._linear(ptr(ws["exf"]), 128, "exif_prior.fusion.0", ptr(ws["t256"]), 256, B, act=1)
@@ -522,11 +535,14 @@ class CognitiveAimModel(nn.Module):
     def _heads(self, ws, B):
         f = self._packed["f32"]
         self._linear(ptr(ws["cat"]), 192, "fusion.0", ptr(ws["fused"]), 192, B, act=1)
-        out = torch.empty(2, B, device=self._packed["device"], dtype=torch.float32)
+        out = ws["out"]
         call("cogaim_heads", ptr(ws["fused"]), 192, ptr(f["decision_head.0.weight"]), ptr(f["decision_head.0.bias"]),
              ptr(f["confidence_head.0.weight"]), ptr(f["confidence_head.0.bias"]),
              ptr(f["confidence_head.2.weight"]), ptr(f["confidence_head.2.bias"]),
              out.data_ptr(), out.data_ptr() + B * 4, B, stream_ptr())
+
+    def _outputs(self, ws):
+        out = ws["out"].clone()
         return out[0].unsqueeze(1), out[1].unsqueeze(1)
 
     def _prepare(self, images: torch.Tensor):
@@ -549,33 +565,70 @@ class CognitiveAimModel(nn.Module):
     def get_features_aligned(self, images, exif_data=None):
         """Fused 192-d features (reference src/model.py:960-1056), one pass."""
         images, ws, B = self._prepare(images)
-        self._features(images, exif_data, ws, B)
-        self._linear(ptr(ws["cat"]), 192, "fusion.0", ptr(ws["fused"]), 192, B, act=1)
+        self._features(images, exif_data, ws, B, graph_key="features")
         self._check_fallback_flags(ws)
         return ws["fused"].clone()
 
-    def _features(self, images, exif_data, ws, B, focal_override=None):
-        """Fills ws['cat'] with [ambient | focal | exif] (zero where a module is absent)."""
+    def _features(self, images, exif_data, ws, B, focal_override=None, heads=True, graph_key=None):
+        """Fills ws['cat'] with [ambient | focal | exif] (zero where a module is absent), then (``heads``)
+        ws['fused'] and ws['out'].  Returns the number of feature columns filled.
+
+        The two launches that read the caller's tensors (patch gather, EXIF gather) run eagerly; the rest of
+        the sequence touches only workspace buffers and weights, so after its first eager run it is captured
+        once per (workspace, variant) and replayed as one HIP graph."""
         if not (self.use_ambient or self.use_focal or (self.use_exif and exif_data is not None)):
             raise RuntimeError("Cognitive modules returned no features!")
         exif_in = self._exif_inputs(exif_data, B) if (self.use_exif and exif_data is not None) else None
-        self._backbone(images, ws)
-        ws["cat"].zero_()
-        col = 0
-        if self.use_ambient:
-            self._ambient(ws, B, col)
-            col += 64
-        if self.use_focal:
-            self._focal(B, ws)
-            if focal_override is None:
-                self._focal_fused_into(ws, B, col)
-            else:
-                focal_override(col)
-            col += 64
+        shape = (B, images.shape[2], images.shape[3])
+        self._backbone(images, shape, ws)
         if exif_in is not None:
-            self._exif(exif_in, ws, B, col)
-            col += 64
-        return col
+            self._exif_prep(exif_in, ws, B)
+        ncols = 64 * (int(self.use_ambient) + int(self.use_focal) + int(exif_in is not None))
+
+        def body():
+            self._backbone(None, shape, ws)
+            ws["cat"].zero_()
+            col = 0
+            if self.use_ambient:
+                self._ambient(ws, B, col)
+                col += 64
+            if self.use_focal:
+                self._focal(B, ws)
+                if focal_override is None:
+                    self._focal_fused_into(ws, B, col)
+                else:
+                    focal_override(col)
+                col += 64
+            if exif_in is not None:
+                self._exif(ws, B, col)
+                col += 64
+            if heads:           # absent modules leave zero columns, as the reference's zero padding does (:1032-1045)
+                self._heads(ws, B)
+
+        self._run(ws, (graph_key, exif_in is not None, heads), body)
+        return ncols
+
+    def _run(self, ws, key, body):
+        """Eager the first time a (workspace, variant) is seen -- which also loads every kernel -- then
+        captured into a HIP graph and replayed.  Per-launch profiling and ``use_graph=False`` stay eager."""
+        from . import _lib
+        if not self.use_graph or key[0] is None or _lib.PROFILE is not None:
+            body()
+            return
+        graphs = ws.setdefault("graphs", {})
+        entry = graphs.get(key)
+        if entry is None:
+            body()
+            graphs[key] = "seen"
+        elif entry == "seen":
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                body()
+            graphs[key] = g
+            g.replay()
+        else:
+            entry.replay()
 
     def get_features(self, images, exif_data=None):
         return self.get_features_aligned(images, exif_data)
@@ -587,8 +640,8 @@ class CognitiveAimModel(nn.Module):
     def forward(self, images, exif_data=None, return_attention=False):
         """(depth [B,1], confidence [B,1]) or (+ attention [B,N] | None)  — reference src/model.py:1064-1155."""
         images, ws, B = self._prepare(images)
-        self._features(images, exif_data, ws, B)
-        depth, conf = self._heads(ws, B)
+        self._features(images, exif_data, ws, B, graph_key="forward")
+        depth, conf = self._outputs(ws)
         self._check_fallback_flags(ws)
         self.fusion_features = ws["fused"].clone()
         attn = ws["attn"].clone() if self.use_focal else None
@@ -627,8 +680,9 @@ class CognitiveAimModel(nn.Module):
         if temp_projection is None:
             lin = nn.Linear(self.feature_dim, 64)
             temp_projection = (lin.weight.detach(), lin.bias.detach())
-        pw = temp_projection[0].to(self._packed["device"], torch.float32).contiguous()
-        pb = temp_projection[1].to(self._packed["device"], torch.float32).contiguous()
+        ws["pw"].copy_(temp_projection[0].reshape(64, D), non_blocking=True)     # static buffers: the captured
+        ws["pb"].copy_(temp_projection[1].reshape(64), non_blocking=True)        # sequence reads these addresses
+        pw, pb = ws["pw"], ws["pb"]
 
         def guided_focal(col):
             st = stream_ptr()
@@ -637,7 +691,8 @@ class CognitiveAimModel(nn.Module):
                  ptr(ws["wt"]), ptr(ws["wtpart"]), B, N, D, st)
             self._linear(ptr(ws["wt"]), D, None, ws["cat"].data_ptr() + col * 4, 192, B, W=pw, bias=pb)
 
-        ncols = self._features(images, exif_data, ws, B, focal_override=guided_focal)
+        ncols = self._features(images, exif_data, ws, B, focal_override=guided_focal,
+                               graph_key=("guided", gdev.data_ptr()) if gkey else None)
         self._check_fallback_flags(ws)
         attn = ws["guided"].clone()
         self._last_attention_weights = attn                # :1212
@@ -646,7 +701,7 @@ class CognitiveAimModel(nn.Module):
             # branch re-runs the standard forward (:1226, :1237-1240); the guided attention stays cached
             out = self.forward(images, exif_data, return_attention)
             return out
-        depth, conf = self._heads(ws, B)
+        depth, conf = self._outputs(ws)
         if return_attention:
             return depth, conf, attn
         return depth, conf

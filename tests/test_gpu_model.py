@@ -188,3 +188,35 @@ def test_high_resolution_eight_iterations():
     assert a.shape == (1, 5476)
     assert e["depth"] <= DEPTH_TOL and e["conf"] <= DEPTH_TOL and e["attn"] <= 3e-2, e
     model.synchronize()
+
+
+def test_graph_replay_equals_eager_launches():
+    """The captured HIP graph replays the same kernels on the same buffers: results are bit-identical to the
+    eager launch sequence, for new inputs on every call, for both forwards, and after new weights are loaded."""
+    model, sd = synth_model_and_sd(2, 4, seed=7, dtype="fp16")
+    eager, _ = synth_model_and_sd(2, 4, seed=7, dtype="fp16")
+    eager.use_graph = False
+    assert model.use_graph
+    proj = (torch.randn(64, 768), torch.randn(64))
+    for call_no in range(4):                                   # 0: eager, 1: capture + replay, 2..: replay
+        x = torch.randn(3, 3, 224, 224, device="cuda")
+        exif = default_exif(3, "cuda")
+        d, c, a = model(x, exif, return_attention=True)
+        d0, c0, a0 = eager(x, exif, return_attention=True)
+        assert torch.equal(d, d0) and torch.equal(c, c0) and torch.equal(a, a0), call_no
+        g = model.forward_with_guidance(x, exif, "top-left", True, temp_projection=proj)
+        g0 = eager.forward_with_guidance(x, exif, "top-left", True, temp_projection=proj)
+        assert all(torch.equal(u, v) for u, v in zip(g, g0)), call_no
+        f, f0 = model.get_features(x, None), eager.get_features(x, None)
+        assert torch.equal(f, f0), call_no
+    ws = next(iter(model._ws.values()))
+    assert sum(isinstance(v, torch.cuda.CUDAGraph) for v in ws["graphs"].values()) == 3
+    # new weights: packed copies move, the graphs must be rebuilt, not replayed on stale pointers
+    sd2 = {k: (v * 1.01 if v.is_floating_point() else v) for k, v in sd.items()}
+    model.load_state_dict(sd2)
+    eager.load_state_dict(sd2)
+    for _ in range(3):
+        x = torch.randn(3, 3, 224, 224, device="cuda")
+        exif = default_exif(3, "cuda")
+        assert all(torch.equal(u, v) for u, v in zip(model(x, exif), eager(x, exif)))
+    model.synchronize()
