@@ -11,7 +11,7 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcogaim.so")
+LIB_PATH = os.environ.get("COGAIM_LIB") or os.path.join(HERE, "libcogaim.so")     # override: A/B runs in tools/
 
 P, I, F, LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 

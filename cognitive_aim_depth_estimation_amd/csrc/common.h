@@ -85,8 +85,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // pointers, reads past num_bytes return zero instead of faulting, and -- unlike the global_ form, which
 // the compiler treats as a flat access and answers with lgkmcnt(0) before every later LDS read -- it
 // leaves the compiler's LDS wait counting exact.
+// (base and extent must be wave-uniform; they are forced into scalar registers here, otherwise the compiler
+// wraps every use of the resource in a per-lane "waterfall" loop)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned num_bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)num_bytes, 0x00020000);
+  const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+  void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)__builtin_amdgcn_readfirstlane(num_bytes), 0x00020000);
 }
 __device__ __forceinline__ void bufload_lds16(__amdgpu_buffer_rsrc_t rsrc, int lane_byte_offset, int wave_byte_offset,
                                               void* lds_wave_base) {
