@@ -541,6 +541,12 @@ class CognitiveAimModel(nn.Module):
              ptr(f["confidence_head.2.weight"]), ptr(f["confidence_head.2.bias"]),
              out.data_ptr(), out.data_ptr() + B * 4, B, stream_ptr())
 
+    def _empty_outputs(self, images, return_attention):
+        z = torch.zeros(0, 1, device=images.device, dtype=torch.float32)
+        n = (images.shape[2] // self.patch_size) * (images.shape[3] // self.patch_size)
+        attn = torch.zeros(0, n, device=images.device) if self.use_focal else None
+        return (z, z.clone(), attn) if return_attention else (z, z.clone())
+
     def _outputs(self, ws):
         out = ws["out"].clone()
         return out[0].unsqueeze(1), out[1].unsqueeze(1)
@@ -639,6 +645,8 @@ class CognitiveAimModel(nn.Module):
     @torch.no_grad()
     def forward(self, images, exif_data=None, return_attention=False):
         """(depth [B,1], confidence [B,1]) or (+ attention [B,N] | None)  — reference src/model.py:1064-1155."""
+        if images.dim() == 4 and images.shape[0] == 0:          # empty batch: empty results, nothing launched
+            return self._empty_outputs(images, return_attention)
         images, ws, B = self._prepare(images)
         self._features(images, exif_data, ws, B, graph_key="forward")
         depth, conf = self._outputs(ws)
@@ -663,6 +671,8 @@ class CognitiveAimModel(nn.Module):
         when omitted a new ``nn.Linear(768, 64)`` is drawn from torch's global RNG exactly
         as the reference does, so guided depth is as irreproducible here as it is there.
         """
+        if images.dim() == 4 and images.shape[0] == 0:
+            return self._empty_outputs(images, return_attention)
         if not self.use_focal or attention_guidance is None:
             if self.use_focal or self.use_ambient:
                 out = self.forward(images, exif_data, True)

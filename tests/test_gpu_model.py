@@ -220,3 +220,16 @@ def test_graph_replay_equals_eager_launches():
         exif = default_exif(3, "cuda")
         assert all(torch.equal(u, v) for u, v in zip(model(x, exif), eager(x, exif)))
     model.synchronize()
+
+
+def test_empty_batch_and_single_image():
+    model, sd = synth_model_and_sd(2, 4, seed=7, dtype="fp16")
+    x0 = torch.zeros(0, 3, 56, 56, device="cuda")
+    d, c, a = model(x0, None, return_attention=True)
+    assert d.shape == (0, 1) and c.shape == (0, 1) and a.shape == (0, 16)
+    g = model.forward_with_guidance(x0, None, "center")
+    assert g[0].shape == (0, 1)
+    x1 = torch.randn(1, 3, 56, 56, device="cuda")
+    d1, c1 = model(x1, default_exif(1, "cuda"))
+    d_ref, c_ref, _ = O.forward(sd, x1.cpu(), default_exif(1), return_attention=True)
+    assert rel_err(d1, d_ref) <= DEPTH_TOL and rel_err(c1, c_ref) <= DEPTH_TOL
