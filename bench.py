@@ -54,6 +54,9 @@ def gemm_flops(name, args):
     elif name == "cogaim_mhsa_fwd":
         B, T, H = args[3], args[4], args[5]
         return 4.0 * B * H * T * T * 64, (B, T, H)
+    elif name == "cogaim_mhsa_qkv_fwd":
+        B, T, H = args[2], args[3], args[4]
+        return 4.0 * B * H * T * T * 64, (B, T, H)
     else:
         return None, None
     return 2.0 * M * N * K, (M, N, K)
@@ -62,7 +65,7 @@ def gemm_flops(name, args):
 # C-ABI entry point -> kernel name in the committed rocprofv3 PMC summaries (profiles/*_hbm_traffic.json)
 _PROFILE_KERNEL = {"cogaim_gemm_bias_gelu_half": "gemm256p<EpiBiasGeluHalf>", "cogaim_gemm_bias_half": "gemm256p<EpiBiasHalf>",
                    "cogaim_gemm_residual_f32": "gemm256p<EpiResidualF32>", "cogaim_gemm_vt": "gemm256p<EpiVT>",
-                   "cogaim_mhsa_fwd": "mhsa", "cogaim_layernorm": "layernorm"}
+                   "cogaim_mhsa_fwd": "mhsa", "cogaim_mhsa_qkv_fwd": "mhsa", "cogaim_layernorm": "layernorm"}
 
 
 def measured_traffic(entry):

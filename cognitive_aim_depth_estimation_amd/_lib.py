@@ -29,6 +29,7 @@ SIGNATURES = {
     "cogaim_gemm_bias_half": [P, P, P, P, I, I, I, I, I, I, I, F, I, P, LL, P],
     "cogaim_gemm_vt": [P, P, P, P, I, I, I, I, I, I, I, I, P, LL, P],
     "cogaim_mhsa_fwd": [P, P, P, I, I, I, I, I, I, P],
+    "cogaim_mhsa_qkv_fwd": [P, P, I, I, I, I, I, P],
     "cogaim_gemm_residual_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P, LL, P],
     "cogaim_gemm_bias_gelu_half": [P, P, P, P, I, I, I, I, I, I, I, P, LL, P],
     "cogaim_focal_prep": [P, LL, P, P, P, I, I, I, I, P],

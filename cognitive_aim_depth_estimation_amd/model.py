@@ -290,9 +290,10 @@ class CognitiveAimModel(nn.Module):
             a = p + "attention.attention."
             layers.append({
                 "g1": sd[p + "norm1.weight"].float().contiguous(), "b1": sd[p + "norm1.bias"].float().contiguous(),
-                "wqk": torch.cat([sd[a + "query.weight"], sd[a + "key.weight"]], 0).to(tdt).contiguous(),
-                "bqk": torch.cat([sd[a + "query.bias"], sd[a + "key.bias"]], 0).float().contiguous(),
-                "wv": sd[a + "value.weight"].to(tdt).contiguous(), "bv": sd[a + "value.bias"].float().contiguous(),
+                "wqkv": torch.cat([sd[a + "query.weight"], sd[a + "key.weight"], sd[a + "value.weight"]], 0)
+                .to(tdt).contiguous(),
+                "bqkv": torch.cat([sd[a + "query.bias"], sd[a + "key.bias"], sd[a + "value.bias"]], 0)
+                .float().contiguous(),
                 "wo": sd[p + "attention.output.dense.weight"].to(tdt).contiguous(),
                 "bo": sd[p + "attention.output.dense.bias"].float().contiguous(),
                 "ls1": sd[p + "layer_scale1.lambda1"].float().contiguous(),
@@ -362,8 +363,8 @@ class CognitiveAimModel(nn.Module):
         ws = {
             "N": N, "T": T, "M": M, "Tp": Tp, "ldS": ldS, "nblk": nblk,
             "x": torch.empty(M, D, **f32), "tokens": torch.empty(M, D, **f32),
-            "h": torch.empty(M, D, **h16), "qk": torch.empty(M, 2 * D, **h16),
-            "vt": torch.zeros(B * H * 64 * Tp, **h16), "ctx": torch.empty(M, D, **h16),
+            "h": torch.empty(M, D, **h16), "qk": torch.empty(M, 3 * D, **h16),     # query | key | value
+            "ctx": torch.empty(M, D, **h16),
             "big": torch.empty(big_bytes, device=dev, dtype=torch.uint8),
             "gemm_ws": torch.empty(call("cogaim_gemm_workspace_bytes"), device=dev, dtype=torch.uint8),
             "rmax": torch.empty(B, N, **f32), "rinv": torch.empty(B, N, **f32),
@@ -404,7 +405,7 @@ class CognitiveAimModel(nn.Module):
         gh, gw = Hi // p, Wi // p
         N, T, M, Tp = ws["N"], ws["T"], ws["M"], ws["Tp"]
         pos = self._table("pos", gh, gw)
-        x, h, qk, vt, ctx, big = (ws[k].data_ptr() for k in ("x", "h", "qk", "vt", "ctx", "big"))
+        x, h, qk, ctx, big = (ws[k].data_ptr() for k in ("x", "h", "qk", "ctx", "big"))
         gw, gwb = ws["gemm_ws"].data_ptr(), ws["gemm_ws"].numel()
         if images is not None:                 # eager: reads the caller's tensor (everything after it is static)
             call("cogaim_im2col", images.data_ptr(), big, B, Hi, Wi, p, pk["pe_kp"], dt, st)
@@ -415,9 +416,9 @@ class CognitiveAimModel(nn.Module):
         eps = self.layer_norm_eps
         for L in pk["layers"]:
             call("cogaim_layernorm", x, ptr(L["g1"]), ptr(L["b1"]), h, M, D, eps, dt, st)
-            call("cogaim_gemm_bias_half", h, ptr(L["wqk"]), ptr(L["bqk"]), qk, M, 2 * D, D, D, D, 2 * D, D, qscale, dt, gw, gwb, st)
-            call("cogaim_gemm_vt", h, ptr(L["wv"]), ptr(L["bv"]), vt, B, T, D, D, D, D, Tp, dt, gw, gwb, st)
-            call("cogaim_mhsa_fwd", qk, vt, ctx, B, T, H, Tp, 2 * D, dt, st)
+            # one projection GEMM for query | key | value (the query columns carry the softmax scale)
+            call("cogaim_gemm_bias_half", h, ptr(L["wqkv"]), ptr(L["bqkv"]), qk, M, 3 * D, D, D, D, 3 * D, D, qscale, dt, gw, gwb, st)
+            call("cogaim_mhsa_qkv_fwd", qk, ctx, B, T, H, 3 * D, dt, st)
             call("cogaim_gemm_residual_f32", ctx, ptr(L["wo"]), ptr(L["bo"]), ptr(L["ls1"]), x, M, D, D, D, D, D, dt, gw, gwb, st)
             call("cogaim_layernorm", x, ptr(L["g2"]), ptr(L["b2"]), h, M, D, eps, dt, st)
             call("cogaim_gemm_bias_gelu_half", h, ptr(L["w1"]), ptr(L["bf1"]), big, M, 4 * D, D, D, D, 4 * D, dt, gw, gwb, st)

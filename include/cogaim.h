@@ -93,6 +93,11 @@ int cogaim_gemm_vt(const void* A, const void* W, const float* bias, void* vt, in
 int cogaim_mhsa_fwd(const void* qk, const void* vt, void* ctx, int B, int T, int H, int Tp, int ldqk, int dtype,
                     void* stream);
 
+/* The same attention on one fused projection buffer (hf:203-234 computes query, key and value from the same
+ * hidden state): qkv 16-bit [B*T, ld], Q (pre-multiplied by dh^-0.5*log2(e)) in cols [0,D), K in [D,2D),
+ * V in [2D,3D), all row-major (no transposed copy of V); ctx 16-bit [B*T, D]. */
+int cogaim_mhsa_qkv_fwd(const void* qkv, void* ctx, int B, int T, int H, int ld, int dtype, void* stream);
+
 /* hf:246-252 output dense + hf:277-278 LayerScale + hf:370 residual, and the same for
  * fc2 (hf:296, 375-378):  x[M,N] += (A . W^T + bias) * layerscale, in place, x fp32. */
 int cogaim_gemm_residual_f32(const void* A, const void* W, const float* bias, const float* layerscale, float* x, int M,

@@ -154,6 +154,25 @@ def test_mhsa(dtype, B, T, H):
     assert torch.allclose(ctx.float(), ref, rtol=tol, atol=tol), float((ctx.float() - ref).abs().max())
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,T,H", [(2, 17, 2), (1, 64, 1), (2, 257, 3), (2, 1370, 12), (1, 130, 2)])
+def test_mhsa_qkv(dtype, B, T, H):
+    """Fused-buffer attention (V read row-major through the LDS transpose read)."""
+    di, tdt = DT[dtype]
+    D = 64 * H
+    q, k, v = rnd(B, T, H, 64), rnd(B, T, H, 64), rnd(B, T, H, 64)
+    qkv = torch.cat([(q * (64 ** -0.5 * LOG2E)).reshape(B * T, D), k.reshape(B * T, D), v.reshape(B * T, D)], 1)
+    qkv = qkv.to(tdt).contiguous()
+    ctx = torch.full((B * T, D), float("nan"), device="cuda", dtype=tdt)
+    call("cogaim_mhsa_qkv_fwd", ptr(qkv), ptr(ctx), B, T, H, 3 * D, di, stream_ptr())
+    qr = qkv[:, :D].float().view(B, T, H, 64).transpose(1, 2) / LOG2E
+    kr = qkv[:, D:2 * D].float().view(B, T, H, 64).transpose(1, 2)
+    vr = qkv[:, 2 * D:].float().view(B, T, H, 64).transpose(1, 2)
+    ref = (torch.softmax(qr @ kr.transpose(2, 3), -1) @ vr).transpose(1, 2).reshape(B * T, D)
+    tol = 2 ** -7 if dtype == "bf16" else 2 ** -9      # P is rounded to 16 bit before P.V
+    assert torch.allclose(ctx.float(), ref, rtol=tol, atol=tol), float((ctx.float() - ref).abs().max())
+
+
 def test_mhsa_spike_rescale():
     """One key that dominates a late tile forces the running-max rescale branch."""
     di, tdt = DT["fp16"]

@@ -25,3 +25,15 @@ for sc in SCALES:
         ts.append(e0.elapsed_time(e1) / 5)
     ms = statistics.median(ts)
     print(f"mhsa dtype={dt}: {ms*1000:.1f} us  {4.0*B*H*T*T*64/ms/1e9:.1f} TF")
+    qkv = (torch.randn(B * T, 3 * D, device="cuda") * sc).to(tdt)
+    ts = []
+    for _ in range(7):
+        call("cogaim_mhsa_qkv_fwd", ptr(qkv), ptr(ctx), B, T, H, 3 * D, dt, stream_ptr())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            call("cogaim_mhsa_qkv_fwd", ptr(qkv), ptr(ctx), B, T, H, 3 * D, dt, stream_ptr())
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 5)
+    ms = statistics.median(ts)
+    print(f"scale {sc} mhsa_qkv dtype={dt}: {ms*1000:.1f} us  {4.0*B*H*T*T*64/ms/1e9:.1f} TF")
