@@ -47,13 +47,8 @@ def gemm_flops(name, args):
     elif name == "cogaim_gemm_batched_f32":
         M, N, K, batch = args[3], args[4], args[5], args[12]
         return 2.0 * M * N * K * batch, (M, N, K, batch)
-    elif name == "cogaim_gemm_vt":
-        M, N, K = args[4] * args[5], args[6], args[7]
     elif name == "cogaim_gemm_patch_embed":
         M, N, K = args[5] * args[6], args[7], args[8]
-    elif name == "cogaim_mhsa_fwd":
-        B, T, H = args[3], args[4], args[5]
-        return 4.0 * B * H * T * T * 64, (B, T, H)
     elif name == "cogaim_mhsa_qkv_fwd":
         B, T, H = args[2], args[3], args[4]
         return 4.0 * B * H * T * T * 64, (B, T, H)
@@ -64,8 +59,8 @@ def gemm_flops(name, args):
 
 # C-ABI entry point -> kernel name in the committed rocprofv3 PMC summaries (profiles/*_hbm_traffic.json)
 _PROFILE_KERNEL = {"cogaim_gemm_bias_gelu_half": "gemm256p<EpiBiasGeluHalf>", "cogaim_gemm_bias_half": "gemm256p<EpiBiasHalf>",
-                   "cogaim_gemm_residual_f32": "gemm256p<EpiResidualF32>", "cogaim_gemm_vt": "gemm256p<EpiVT>",
-                   "cogaim_mhsa_fwd": "mhsa", "cogaim_mhsa_qkv_fwd": "mhsa", "cogaim_layernorm": "layernorm"}
+                   "cogaim_gemm_residual_f32": "gemm256p<EpiResidualF32>",
+                   "cogaim_mhsa_qkv_fwd": "mhsa", "cogaim_layernorm": "layernorm"}
 
 
 def measured_traffic(entry):

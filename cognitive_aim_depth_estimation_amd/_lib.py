@@ -27,8 +27,6 @@ SIGNATURES = {
     "cogaim_cls_row": [P, P, P, I, I, I, P],
     "cogaim_layernorm": [P, P, P, P, I, I, F, I, P],
     "cogaim_gemm_bias_half": [P, P, P, P, I, I, I, I, I, I, I, F, I, P, LL, P],
-    "cogaim_gemm_vt": [P, P, P, P, I, I, I, I, I, I, I, I, P, LL, P],
-    "cogaim_mhsa_fwd": [P, P, P, I, I, I, I, I, I, P],
     "cogaim_mhsa_qkv_fwd": [P, P, I, I, I, I, I, P],
     "cogaim_gemm_residual_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P, LL, P],
     "cogaim_gemm_bias_gelu_half": [P, P, P, P, I, I, I, I, I, I, I, P, LL, P],

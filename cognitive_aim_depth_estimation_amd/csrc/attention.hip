@@ -8,8 +8,10 @@
 //    and the only cross-lane step per tile is one v_permlane32_swap;
 //  * the S^T accumulator (rows = keys) is converted to 16-bit in place and fed
 //    straight back as the B operand of O^T += V^T P^T (no LDS round trip);
-//  * V arrives pre-transposed per head ([d][token], written that way by the
-//    QKV GEMM epilogue) so the A operand of that product is key-contiguous.
+//  * V stays row-major ([token][d], straight out of the fused QKV projection): its
+//    tiles are staged [key][d] in LDS and read with ds_read_b64_tr_b16, which hands
+//    each lane 4 consecutive keys of its d column -- the A operand of O^T += V^T P^T
+//    without a transposed copy in memory.
 // Q is expected pre-multiplied by dh^-0.5 * log2(e): softmax runs on exp2.
 #include "common.h"
 
@@ -17,194 +19,8 @@ namespace {
 
 constexpr int KV = 64;            // keys per tile
 constexpr int QB = 128;           // queries per block (4 waves x 32)
-constexpr int K_TILE = KV * 128;  // K tile: 64 keys x 64 d x 2 B, chunk-swizzled
-constexpr int V_ROW = 136;        // V^T tile row stride in bytes (64 keys + 8 B pad: conflict-free ds_read_b64)
-constexpr int V_TILE = 64 * V_ROW;
+constexpr int K_TILE = KV * 128;  // K and V tiles: 64 keys x 64 d x 2 B, chunk-swizzled
 constexpr float RESCALE_THR = 6.0f;   // log2 units
-
-template <class T>
-__global__ __launch_bounds__(256, 2) void mhsa_kernel(const T* __restrict__ qk, const T* __restrict__ vt,
-                                                   T* __restrict__ ctx, int Tn, int H, int Tp, int ldqk, int D) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE + 2 * V_TILE];
-  using Hf = Half<T>;
-  using v8 = typename Hf::v8;
-  typedef T v4 __attribute__((ext_vector_type(4)));
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ql = lane & 31, hh = lane >> 5;
-  // Workgroups are dealt round-robin over the 8 XCDs (private L2 each): remap the linear id so that the
-  // query blocks of one (image, head) -- which all stream the same K/V -- are neighbours on ONE XCD.
-  const int nqb = (Tn + QB - 1) / QB;
-  int lid;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int bh = lid / nqb, b = bh / H, h = bh - b * H;
-  const int q0 = (lid - bh * nqb) * QB + wave * 32;
-  const size_t row0 = (size_t)b * Tn;
-
-  // Q fragments: B operand, lane (q = ql, half hh) holds Q[q][16 s + 8 hh .. +7]
-  v8 qf[4];
-  {
-    int q = q0 + ql; q = q < Tn ? q : Tn - 1;
-    const T* qp = qk + (row0 + q) * ldqk + h * 64 + 8 * hh;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const v8*>(qp + 16 * s);
-  }
-
-  // staging assignment: thread handles 16-B chunks idx = tid and tid + 256 of each tile
-  const T* kbase = qk + D + h * 64;
-  const T* vbase = vt + (size_t)bh * 64 * Tp;
-  // (explicit scalars, not arrays: arrays captured by the staging code end up in scratch)
-  uint4 kreg0, kreg1;
-  uint2 vreg0a, vreg0b, vreg1a, vreg1b;
-  const int sr0 = tid >> 3, sr1 = sr0 + 32, sc = tid & 7;
-#define LOAD_TILE(kv0_)                                                                          \
-  {                                                                                              \
-    int key0 = (kv0_) + sr0; key0 = key0 < Tn ? key0 : Tn - 1;                                   \
-    int key1 = (kv0_) + sr1; key1 = key1 < Tn ? key1 : Tn - 1;                                   \
-    kreg0 = *reinterpret_cast<const uint4*>(kbase + (row0 + key0) * ldqk + sc * 8);              \
-    kreg1 = *reinterpret_cast<const uint4*>(kbase + (row0 + key1) * ldqk + sc * 8);              \
-    const uint2* v0 = reinterpret_cast<const uint2*>(vbase + (size_t)sr0 * Tp + (kv0_) + sc * 8); \
-    const uint2* v1 = reinterpret_cast<const uint2*>(vbase + (size_t)sr1 * Tp + (kv0_) + sc * 8); \
-    vreg0a = v0[0]; vreg0b = v0[1]; vreg1a = v1[0]; vreg1b = v1[1];                              \
-  }
-#define STORE_TILE(buf_)                                                                         \
-  {                                                                                              \
-    char* ks_ = smem + (buf_) * K_TILE;                                                          \
-    char* vs_ = smem + 2 * K_TILE + (buf_) * V_TILE;                                             \
-    *reinterpret_cast<uint4*>(ks_ + sr0 * 128 + ((sc ^ ((sr0 >> 1) & 7)) << 4)) = kreg0;         \
-    *reinterpret_cast<uint4*>(ks_ + sr1 * 128 + ((sc ^ ((sr1 >> 1) & 7)) << 4)) = kreg1;         \
-    uint2* p0 = reinterpret_cast<uint2*>(vs_ + sr0 * V_ROW + sc * 16);                           \
-    uint2* p1 = reinterpret_cast<uint2*>(vs_ + sr1 * V_ROW + sc * 16);                           \
-    p0[0] = vreg0a; p0[1] = vreg0b; p1[0] = vreg1a; p1[1] = vreg1b;                              \
-  }
-
-  f32x16 o[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-  float m_run = 0.f, l_run = 0.f;
-
-  const int nt = (Tn + KV - 1) / KV;
-  LOAD_TILE(0);
-  STORE_TILE(0);
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
-    const int kv0 = t * KV;
-    if (t + 1 < nt) LOAD_TILE(kv0 + KV);
-    const char* ks = smem + (t & 1) * K_TILE;
-    const char* vs = smem + 2 * K_TILE + (t & 1) * V_TILE;
-
-    // S^T = K Q^T - m_run : s[kb][i] = S^T[key kb*32 + (i&3) + 8(i>>2) + 4hh][query ql], already relative
-    // to the running maximum (the accumulator starts at -m_run, so no subtraction pass is needed)
-    f32x16 s[2];
-    const float neg_m = -m_run;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s[kb][i] = neg_m;
-      const int r = kb * 32 + ql;
-      const int sw = (r >> 1) & 7;
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const v8 kf = *reinterpret_cast<const v8*>(ks + r * 128 + (((2 * s4 + hh) ^ sw) << 4));
-        s[kb] = Hf::mfma32(kf, qf[s4], s[kb]);
-      }
-    }
-    if (kv0 + KV > Tn) {   // mask keys past the sequence end (last tile only)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (key >= Tn) s[kb][i] = -INFINITY;
-        }
-    }
-    // tile maximum per query column (lane-local + one half swap), relative to m_run
-    float mx;
-    {   // four independent chains (a single 31-deep dependent chain of v_max would serialise the wave)
-      float m4[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) m4[c] = fmaxf(s[0][c], s[1][c]);
-#pragma unroll
-      for (int i = 4; i < 16; ++i) m4[i & 3] = fmaxf(m4[i & 3], fmaxf(s[0][i], s[1][i]));
-      mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-    }
-    {
-      const unsigned u = __float_as_uint(mx);
-      auto sw2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-      mx = fmaxf(__uint_as_float(sw2[0]), __uint_as_float(sw2[1]));
-    }
-    // Deferred rescale: the running maximum only moves when some query of the wave sees a score more
-    // than RESCALE_THR (log2 units) above it; until then exp2 runs on the accumulator as it is and the
-    // probabilities are bounded by 2^RESCALE_THR, exact in 16-bit floating point.  The first tile always
-    // sets the maximum (m_run starts at 0 there).
-    const bool rescale = (t == 0) || !__all(mx <= RESCALE_THR);
-    if (rescale) {
-      const float d = (t == 0) ? mx : fmaxf(mx, 0.f);
-      const float alpha = __builtin_amdgcn_exp2f(-d);
-      m_run += d;
-      l_run *= alpha;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        o[0][i] *= alpha; o[1][i] *= alpha;
-        s[0][i] -= d; s[1][i] -= d;
-      }
-    }
-    float l4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        s[kb][i] = __builtin_amdgcn_exp2f(s[kb][i]);
-        l4[i & 3] += s[kb][i];
-      }
-    l_run += (l4[0] + l4[1]) + (l4[2] + l4[3]);
-
-    // O^T += V^T P^T : A = V^T fragment (rows = d), B = P^T fragment (the S^T registers)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int ks2 = 0; ks2 < 2; ++ks2) {
-        v8 pf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (T)s[kb][8 * ks2 + j];
-        const int key = kb * 32 + 16 * ks2 + 4 * hh;   // element j -> key + 8(j>>2) + (j&3)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const char* vp = vs + (dt * 32 + ql) * V_ROW + key * 2;
-          const v4 lo = *reinterpret_cast<const v4*>(vp);
-          const v4 hi = *reinterpret_cast<const v4*>(vp + 16);
-          o[dt] = Hf::mfma32(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), pf, o[dt]);
-        }
-      }
-
-    if (t + 1 < nt) STORE_TILE((t + 1) & 1);
-    __syncthreads();
-  }
-
-  // combine the two lane halves' partial sums, normalise, store ctx[b*T+q][h*64 + d]
-  {
-    const unsigned u = __float_as_uint(l_run);
-    auto sw2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    l_run = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
-  }
-  const float inv = 1.0f / l_run;
-  const int q = q0 + ql;
-  if (q < Tn) {
-    T* op = ctx + (row0 + q) * D + h * 64 + 4 * hh;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<Half4<T>*>(op + dt * 32 + 8 * g) =
-            to_half4<T>(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-  }
-}
-
-#undef LOAD_TILE
-#undef STORE_TILE
 
 template <class T>
 __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ qk, T* __restrict__ ctx, int Tn, int H, int ldqk,
@@ -405,26 +221,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
 
 extern "C" {
 
-// qk: [B*T, ldqk] 16-bit, Q (pre-scaled by 64^-0.5 * log2 e) in columns [0,D), K in [D,2D);
-// vt: [B*H, 64, Tp] 16-bit (Tp multiple of 64, >= T; columns past T may hold anything finite);
-// ctx: [B*T, D] 16-bit.  D = 64*H.
-int cogaim_mhsa_fwd(const void* qk, const void* vt, void* ctx, int B, int T, int H, int Tp, int ldqk, int dtype,
-                    void* stream) {
-  if (B <= 0 || T <= 0 || H <= 0 || (Tp & 63) || Tp < T || (ldqk & 7)) return COGAIM_EINVAL;
-  const int D = 64 * H;
-  dim3 grid(((T + QB - 1) / QB) * B * H);
-  if (dtype == 0)
-    hipLaunchKernelGGL(mhsa_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)qk,
-                       (const __bf16*)vt, (__bf16*)ctx, T, H, Tp, ldqk, D);
-  else if (dtype == 1)
-    hipLaunchKernelGGL(mhsa_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)qk,
-                       (const _Float16*)vt, (_Float16*)ctx, T, H, Tp, ldqk, D);
-  else
-    return COGAIM_EINVAL;
-  return COGAIM_LAUNCH_CHECK();
-}
-
-// Same attention on a fused projection buffer: qkv 16-bit [B*T, ld] with Q (pre-scaled by 64^-0.5 * log2 e) in
+// qkv 16-bit [B*T, ld] with Q (pre-scaled by 64^-0.5 * log2 e) in
 // columns [0, D), K in [D, 2D), V in [2D, 3D), all row-major; ctx 16-bit [B*T, D].  No transposed copy of V:
 // the kernel reads its V tiles through the LDS transpose read.
 int cogaim_mhsa_qkv_fwd(const void* qkv, void* ctx, int B, int T, int H, int ld, int dtype, void* stream) {

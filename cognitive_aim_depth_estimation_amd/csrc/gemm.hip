@@ -182,35 +182,6 @@ struct EpiPatchEmbed {                             // token row b*T+1+p = acc + 
   }
 };
 
-template <class T> struct EpiVT {                  // V^T[(b*H+h)*64 + d][t] (row length Tp), plain orientation
-  static constexpr bool kWide = false, kResidual = false;
-  T* vt; const float* bias; int T_, Tp, M, N;
-  __device__ __forceinline__ float load_col1(int n) const { return n < N ? bias[n] : 0.f; }
-  __device__ __forceinline__ void finish4m(int, int m0, int n, f32x4 v, float bi) const {
-    if (m0 >= M || n >= N) return;
-    const int b = m0 / T_, t = m0 - b * T_;
-    const int H = N >> 6;
-    T* row = vt + ((size_t)(b * H + (n >> 6)) * 64 + (n & 63)) * Tp;
-    if (t + 3 < T_ && m0 + 3 < M && ((t & 3) == 0)) {
-      *reinterpret_cast<Half4<T>*>(row + t) = to_half4<T>(v[0] + bi, v[1] + bi, v[2] + bi, v[3] + bi);
-    } else if (t + 3 < T_ && m0 + 3 < M && ((t & 1) == 0)) {      // image offset b*T is only 4-byte aligned
-      const Half4<T> h = to_half4<T>(v[0] + bi, v[1] + bi, v[2] + bi, v[3] + bi);
-      reinterpret_cast<uint32_t*>(row + t)[0] = reinterpret_cast<const uint32_t*>(&h)[0];
-      reinterpret_cast<uint32_t*>(row + t)[1] = reinterpret_cast<const uint32_t*>(&h)[1];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int m = m0 + j;
-        if (m < M) {
-          const int bb = m / T_, tt = m - bb * T_;
-          vt[((size_t)(bb * H + (n >> 6)) * 64 + (n & 63)) * Tp + tt] = (T)(v[j] + bi);
-        }
-      }
-    }
-  }
-  __device__ __forceinline__ void store4m(int, int m0, int n, f32x4 v) const { finish4m(0, m0, n, v, load_col1(n)); }
-};
-
 // bijective XCD-aware remap: blocks that share an XCD (bid % 8) get a contiguous tile range
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -402,16 +373,6 @@ int cogaim_gemm_patch_embed(const void* cols, const void* W, const float* bias, 
   EpiPatchEmbed e{x, bias, pos, D, P, B * P};
   return DISPATCH_T(dtype, (launch<__bf16, EpiPatchEmbed, true>(g, e, 1, (hipStream_t)stream, false, workspace, workspace_bytes)),
                     (launch<_Float16, EpiPatchEmbed, true>(g, e, 1, (hipStream_t)stream, false, workspace, workspace_bytes)));
-}
-
-// V projection written transposed per head: vt[(b*H+h)*64+d][t] = A[b*T+t] . W[h*64+d] + bias, row length Tp.
-int cogaim_gemm_vt(const void* A, const void* W, const float* bias, void* vt, int B, int T, int D, int K, int lda,
-                   int ldw, int Tp, int dtype, void* workspace, long long workspace_bytes, void* stream) {
-  if ((D & 63) || Tp < T || (Tp & 3)) return COGAIM_EINVAL;
-  GemmShape g{A, W, B * T, D, K, lda, ldw, 0, 0};
-  return DISPATCH_T(dtype,
-      (launch<__bf16, EpiVT<__bf16>, false>(g, {(__bf16*)vt, bias, T, Tp, B * T, D}, 1, (hipStream_t)stream, false, workspace, workspace_bytes)),
-      (launch<_Float16, EpiVT<_Float16>, false>(g, {(_Float16*)vt, bias, T, Tp, B * T, D}, 1, (hipStream_t)stream, false, workspace, workspace_bytes)));
 }
 
 // Tuning knob: 0 = 128x128 kernel for every problem; 1 = 256x256 kernel, one tile per workgroup;

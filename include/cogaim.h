@@ -81,21 +81,10 @@ int cogaim_gemm_bias_half(const void* A, const void* W, const float* bias, void*
                           int ldw, int ldc, int scale_cols, float scale, int dtype, void* workspace,
                           long long workspace_bytes, void* stream);
 
-/* hf:201,212 value Linear, written transposed per head for the attention kernel:
- * vt[(b*H+h)*64 + d][t] = A[b*T+t] . W[h*64+d] + bias[h*64+d];  rows are Tp long (Tp >= T, multiple of 64);
- * columns t >= T are never written and must be finite (zero them once). */
-int cogaim_gemm_vt(const void* A, const void* W, const float* bias, void* vt, int B, int T, int D, int K, int lda,
-                   int ldw, int Tp, int dtype, void* workspace, long long workspace_bytes, void* stream);
-
-/* hf:153-178 softmax(Q K^T * dh^-0.5) V for all heads (dh = 64), flash style.
- * qk 16-bit [B*T, ldqk]: Q pre-multiplied by dh^-0.5*log2(e) in cols [0,D), K in [D,2D);
- * vt as written by cogaim_gemm_vt; ctx 16-bit [B*T, D]. */
-int cogaim_mhsa_fwd(const void* qk, const void* vt, void* ctx, int B, int T, int H, int Tp, int ldqk, int dtype,
-                    void* stream);
-
-/* The same attention on one fused projection buffer (hf:203-234 computes query, key and value from the same
- * hidden state): qkv 16-bit [B*T, ld], Q (pre-multiplied by dh^-0.5*log2(e)) in cols [0,D), K in [D,2D),
- * V in [2D,3D), all row-major (no transposed copy of V); ctx 16-bit [B*T, D]. */
+/* hf:153-178 softmax(Q K^T * dh^-0.5) V for all heads (dh = 64), flash style, on the fused projection buffer
+ * (hf:203-234 computes query, key and value from the same hidden state: one cogaim_gemm_bias_half with the
+ * three weights stacked): qkv 16-bit [B*T, ld], Q (pre-multiplied by dh^-0.5*log2(e)) in cols [0,D), K in
+ * [D,2D), V in [2D,3D), all row-major (no transposed copy of V); ctx 16-bit [B*T, D]. */
 int cogaim_mhsa_qkv_fwd(const void* qkv, void* ctx, int B, int T, int H, int ld, int dtype, void* stream);
 
 /* hf:246-252 output dense + hf:277-278 LayerScale + hf:370 residual, and the same for

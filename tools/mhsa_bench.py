@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU micro-benchmark of cogaim_mhsa_fwd at the B=32 @518 shape.  Tuning aid only."""
+"""GPU micro-benchmark of cogaim_mhsa_qkv_fwd at the B=32 @518 shape.  Tuning aid only."""
 import os, sys, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,21 +10,8 @@ torch.manual_seed(0)
 SCALES = [float(x) for x in os.environ.get("SCALES", "0.6").split(",")]
 for sc in SCALES:
   for dt, tdt in ((1, torch.float16), (0, torch.bfloat16)):
-    qk = (torch.randn(B * T, 2 * D, device="cuda") * sc).to(tdt)
     print("scale", sc, end=" ")
-    vt = torch.randn(B * H * 64 * Tp, device="cuda").to(tdt)
     ctx = torch.empty(B * T, D, device="cuda", dtype=tdt)
-    ts = []
-    for _ in range(7):
-        call("cogaim_mhsa_fwd", ptr(qk), ptr(vt), ptr(ctx), B, T, H, Tp, 2 * D, dt, stream_ptr())
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            call("cogaim_mhsa_fwd", ptr(qk), ptr(vt), ptr(ctx), B, T, H, Tp, 2 * D, dt, stream_ptr())
-        e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) / 5)
-    ms = statistics.median(ts)
-    print(f"mhsa dtype={dt}: {ms*1000:.1f} us  {4.0*B*H*T*T*64/ms/1e9:.1f} TF")
     qkv = (torch.randn(B * T, 3 * D, device="cuda") * sc).to(tdt)
     ts = []
     for _ in range(7):
