@@ -48,31 +48,59 @@ __global__ __launch_bounds__(256) void focal_colsum_kernel(const float* __restri
   const int r0 = blk * CS_ROWS;
   const float* Sb = S + b * strideS;
   if constexpr (STATS) {
-    for (int rr = wave; rr < CS_ROWS; rr += 4) {
-      const int row = r0 + rr;
-      if (row < N) {
-        const float* sr = Sb + (size_t)row * ldS;   // rows are 16-B aligned (ldS % 4 == 0)
-        const int n4 = N & ~3;
-        float mx = -INFINITY;
-        for (int c = lane * 4; c < n4; c += 256) {
-          const float4 v = *reinterpret_cast<const float4*>(sr + c);
-          mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    // each wave owns 16 of the block's rows and walks them four at a time: the four rows' loads and the four
+    // wave reductions are independent, which is what hides the memory latency of this short, strided pass
+    const int n4 = N & ~3;
+    for (int g = 0; g < CS_ROWS / 16; ++g) {
+      const float* sr[4];
+      bool ok[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = r0 + wave + 4 * (4 * g + k);
+        ok[k] = row < N;
+        sr[k] = Sb + (size_t)(ok[k] ? row : N - 1) * ldS;       // rows are 16-B aligned (ldS % 4 == 0)
+      }
+      float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      for (int c = lane * 4; c < n4; c += 256) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 v = *reinterpret_cast<const float4*>(sr[k] + c);
+          mx[k] = fmaxf(fmaxf(mx[k], fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
         }
-        for (int c = n4 + lane; c < N; c += 64) mx = fmaxf(mx, sr[c]);
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int c = lane * 4; c < n4; c += 256) {
-          const float4 v = *reinterpret_cast<const float4*>(sr + c);
-          sum += (__builtin_amdgcn_exp2f(v.x - mx) + __builtin_amdgcn_exp2f(v.y - mx)) +
-                 (__builtin_amdgcn_exp2f(v.z - mx) + __builtin_amdgcn_exp2f(v.w - mx));
+      }
+      for (int c = n4 + lane; c < N; c += 64)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], sr[k][c]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o, 64));
+      float sum[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int c = lane * 4; c < n4; c += 256) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 v = *reinterpret_cast<const float4*>(sr[k] + c);
+          sum[k] += (__builtin_amdgcn_exp2f(v.x - mx[k]) + __builtin_amdgcn_exp2f(v.y - mx[k])) +
+                    (__builtin_amdgcn_exp2f(v.z - mx[k]) + __builtin_amdgcn_exp2f(v.w - mx[k]));
         }
-        for (int c = n4 + lane; c < N; c += 64) sum += __builtin_amdgcn_exp2f(sr[c] - mx);
-        sum = wave_sum(sum);
-        if (lane == 0) {
-          m_s[rr] = mx; i_s[rr] = 1.0f / sum;
-          rmax[(size_t)b * N + row] = mx; rinv[(size_t)b * N + row] = 1.0f / sum;
+      }
+      for (int c = n4 + lane; c < N; c += 64)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sum[k] += __builtin_amdgcn_exp2f(sr[k][c] - mx[k]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sum[k] += __shfl_xor(sum[k], o, 64);
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int rr = wave + 4 * (4 * g + k), row = r0 + rr;
+          if (ok[k]) {
+            m_s[rr] = mx[k]; i_s[rr] = 1.0f / sum[k];
+            rmax[(size_t)b * N + row] = mx[k]; rinv[(size_t)b * N + row] = 1.0f / sum[k];
+          } else { m_s[rr] = 0.f; i_s[rr] = 0.f; }
         }
-      } else if (lane == 0) { m_s[rr] = 0.f; i_s[rr] = 0.f; }
+      }
     }
   } else {
     if (tid < CS_ROWS) {
@@ -85,10 +113,19 @@ __global__ __launch_bounds__(256) void focal_colsum_kernel(const float* __restri
   __syncthreads();
   const int rows = min(CS_ROWS, N - r0);
   for (int c = tid; c < N; c += 256) {
-    float acc = 0.f;
-    for (int rr = 0; rr < rows; ++rr)
-      acc += __builtin_amdgcn_exp2f(Sb[(size_t)(r0 + rr) * ldS + c] - m_s[rr]) * i_s[rr];
-    part[((size_t)b * nblk + blk) * N + c] = acc;
+    const float* sp = Sb + (size_t)r0 * ldS + c;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;      // row order inside each chain is fixed: deterministic
+    int rr = 0;
+    for (; rr + 3 < rows; rr += 4) {
+      const float v0 = sp[(size_t)rr * ldS], v1 = sp[(size_t)(rr + 1) * ldS];
+      const float v2 = sp[(size_t)(rr + 2) * ldS], v3 = sp[(size_t)(rr + 3) * ldS];
+      acc0 += __builtin_amdgcn_exp2f(v0 - m_s[rr]) * i_s[rr];
+      acc1 += __builtin_amdgcn_exp2f(v1 - m_s[rr + 1]) * i_s[rr + 1];
+      acc2 += __builtin_amdgcn_exp2f(v2 - m_s[rr + 2]) * i_s[rr + 2];
+      acc3 += __builtin_amdgcn_exp2f(v3 - m_s[rr + 3]) * i_s[rr + 3];
+    }
+    for (; rr < rows; ++rr) acc0 += __builtin_amdgcn_exp2f(sp[(size_t)rr * ldS] - m_s[rr]) * i_s[rr];
+    part[((size_t)b * nblk + blk) * N + c] = (acc0 + acc1) + (acc2 + acc3);
   }
 }
 
