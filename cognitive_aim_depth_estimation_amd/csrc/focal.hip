@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void focal_prep_kernel(const float* __restrict
   }
 }
 
-constexpr int CS_ROWS = 64;   // score rows per block
+constexpr int CS_ROWS = 32;   // score rows per block
 
 // part[b][blk][c] = sum over the block's rows n of w_n * exp2(S[n][c] - m_n) * inv_n
 // STATS: m_n, inv_n are computed here (and stored); w_n = 1.   else: read m, inv; w_n = roww[b][n].
