@@ -15,21 +15,22 @@
 
 namespace {
 
+// One wave per token row (no per-element index arithmetic), 16-byte loads, 8-byte stores.
 template <class T>
 __global__ __launch_bounds__(256) void focal_prep_kernel(const float* __restrict__ tok, long long tok_stride_b,
                                                          const float* __restrict__ scale, const float* __restrict__ pe,
                                                          T* __restrict__ out, int B, int N, int D) {
-  const int dv = D >> 2;
-  const long long total = (long long)B * N * dv;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % dv);
-    const long long row = i / dv;
-    const int n = (int)(row % N), b = (int)(row / N);
-    const float4 x = reinterpret_cast<const float4*>(tok + b * tok_stride_b + (size_t)n * D)[c];
-    const float4 p = reinterpret_cast<const float4*>(pe + (size_t)n * D)[c];
-    const float s = scale ? scale[row] : 1.0f;
-    reinterpret_cast<Half4<T>*>(out + row * D)[c] =
-        to_half4<T>(x.x * s + p.x, x.y * s + p.y, x.z * s + p.z, x.w * s + p.w);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * N) return;
+  const int b = row / N, n = row - b * N;
+  const float4* x4 = reinterpret_cast<const float4*>(tok + b * tok_stride_b + (size_t)n * D);
+  const float4* p4 = reinterpret_cast<const float4*>(pe + (size_t)n * D);
+  Half4<T>* o4 = reinterpret_cast<Half4<T>*>(out + (size_t)row * D);
+  const float s = scale ? scale[row] : 1.0f;
+  for (int c = lane; c < (D >> 2); c += 64) {
+    const float4 x = x4[c], p = p4[c];
+    o4[c] = to_half4<T>(x.x * s + p.x, x.y * s + p.y, x.z * s + p.z, x.w * s + p.w);
   }
 }
 
@@ -262,7 +263,8 @@ int cogaim_focal_colsum_rows() { return CS_ROWS; }
 int cogaim_focal_prep(const float* tok, long long tok_stride_b, const float* scale, const float* pe, void* out, int B,
                       int N, int D, int dtype, void* stream) {
   if (B <= 0 || N <= 0 || (D & 3)) return COGAIM_EINVAL;
-  const int g = grid_for((long long)B * N * (D >> 2));
+  if ((long long)B * N >= (1ll << 31)) return COGAIM_EINVAL;
+  const int g = (B * N + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == 0) hipLaunchKernelGGL(focal_prep_kernel<__bf16>, dim3(g), dim3(256), 0, st, tok, tok_stride_b, scale, pe, (__bf16*)out, B, N, D);
   else if (dtype == 1) hipLaunchKernelGGL(focal_prep_kernel<_Float16>, dim3(g), dim3(256), 0, st, tok, tok_stride_b, scale, pe, (_Float16*)out, B, N, D);
