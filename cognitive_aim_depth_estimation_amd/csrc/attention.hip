@@ -89,9 +89,9 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
     vtr0 = (4 * hh + q) * 128 + chunk * 16 + 8 * (p & 1);
     vtr1 = vtr0 ^ 64;
   }
-  f32x16 o[2];
+  f32x16 o[2], negm;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; negm[i] = 0.f; }
   float m_run = 0.f, l_run = 0.f;
 
   const int nt = (Tn + KV - 1) / KV;
@@ -107,17 +107,14 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
     // S^T = K Q^T - m_run : s[kb][i] = S^T[key kb*32 + (i&3) + 8(i>>2) + 4hh][query ql], already relative
     // to the running maximum (the accumulator starts at -m_run, so no subtraction pass is needed)
     f32x16 s[2];
-    const float neg_m = -m_run;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s[kb][i] = neg_m;
       const int r = kb * 32 + ql;
       const int sw = (r >> 1) & 7;
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const v8 kf = *reinterpret_cast<const v8*>(ks + r * 128 + (((2 * s4 + hh) ^ sw) << 4));
-        s[kb] = Hf::mfma32(kf, qf[s4], s[kb]);
+        s[kb] = Hf::mfma32(kf, qf[s4], s4 == 0 ? negm : s[kb]);     // negm: 16 registers holding -m_run
       }
     }
     if (kv0 + KV > Tn) {   // mask keys past the sequence end (last tile only)
@@ -136,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
 #pragma unroll
       for (int c = 0; c < 4; ++c) m4[c] = fmaxf(s[0][c], s[1][c]);
 #pragma unroll
-      for (int i = 4; i < 16; ++i) m4[i & 3] = fmaxf(m4[i & 3], fmaxf(s[0][i], s[1][i]));
+      for (int i = 4; i < 16; ++i) m4[i & 3] = fmaxf(fmaxf(m4[i & 3], s[0][i]), s[1][i]);      // v_max3_f32
       mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
     }
     {
@@ -158,6 +155,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
       for (int i = 0; i < 16; ++i) {
         o[0][i] *= alpha; o[1][i] *= alpha;
         s[0][i] -= d; s[1][i] -= d;
+        negm[i] = -m_run;
       }
     }
     float l4[4] = {0.f, 0.f, 0.f, 0.f};
