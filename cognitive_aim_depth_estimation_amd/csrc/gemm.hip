@@ -32,17 +32,19 @@ struct GemmShape {
 //     load_cols(n0, b, l)            column constants of columns n0..n0+3 (bias, LayerScale)
 //     load_res(z, m, n0)             per-element addend (kResidual epilogues only)
 //     finish4n(z, m, n0, acc, b, l, r)
-//     finish16n(z, m, n0, acc[4], b[4])      kWide epilogues: 16 adjacent columns per lane
+//     finish8x2n(z, m, n0, acc[4], b[4])     kWide epilogues: columns [n0, n0+8) from acc[0..1], [n0+32, n0+40) from acc[2..3]
 //     store4n(z, m, n0, acc)         all of the above for one fragment (128x128 kernel, fix-up)
 //   plain orientation (a lane owns 4 consecutive rows of one column): load_col1 / finish4m / store4m.
 
 template <class T>
-__device__ __forceinline__ void store_half16(T* p, const float (&y)[16]) {   // 16 contiguous 16-bit values, 16-B aligned
-  alignas(16) T h[16];
+__device__ __forceinline__ void store_half8(T* p, const float (&y)[8]) {   // 8 contiguous 16-bit values, 16-B aligned
+  alignas(16) T h[8];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) h[i] = (T)y[i];
-  reinterpret_cast<uint4*>(p)[0] = reinterpret_cast<const uint4*>(h)[0];
-  reinterpret_cast<uint4*>(p)[1] = reinterpret_cast<const uint4*>(h)[1];
+  for (int i = 0; i < 8; ++i) h[i] = (T)y[i];
+  // streaming store: a tile's 128 KB would otherwise be allocated in L2, where the 256 CUs' simultaneous
+  // epilogues evict the operand panels; the consumers re-read these outputs from HBM either way
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(*reinterpret_cast<const u4*>(h), reinterpret_cast<u4*>(p));
 }
 
 __device__ __forceinline__ float4 ldg4(const float* p, bool ok) {
@@ -60,43 +62,47 @@ template <class T> struct EpiBiasHalf {           // out16 = (acc + bias) [* sca
     *reinterpret_cast<Half4<T>*>(out + (size_t)m * ldc + n0) =
         to_half4<T>((v[0] + b.x) * s, (v[1] + b.y) * s, (v[2] + b.z) * s, (v[3] + b.w) * s);
   }
-  __device__ __forceinline__ void finish16n(int, int m, int n0, const f32x4 (&v)[4], const float4 (&b)[4]) const {
-    if (m >= M || n0 >= N) return;
-    if (n0 + 16 > N || (ldc & 7) || (scale_cols & 15)) {
+  __device__ __forceinline__ void finish8x2n(int, int m, int n0, const f32x4 (&v)[4], const float4 (&b)[4]) const {
+    if (m >= M) return;
+    if (n0 + 40 > N || (ldc & 7) || (scale_cols & 7)) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) finish4n(0, m, n0 + 4 * q, v[q], b[q], b[q], b[q]);
+      for (int q = 0; q < 4; ++q) finish4n(0, m, n0 + 4 * (q & 1) + 32 * (q >> 1), v[q], b[q], b[q], b[q]);
       return;
     }
-    const float s = n0 < scale_cols ? scale : 1.0f;
-    float y[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      y[4 * q] = (v[q][0] + b[q].x) * s; y[4 * q + 1] = (v[q][1] + b[q].y) * s;
-      y[4 * q + 2] = (v[q][2] + b[q].z) * s; y[4 * q + 3] = (v[q][3] + b[q].w) * s;
+    for (int h = 0; h < 2; ++h) {
+      const float s = n0 + 32 * h < scale_cols ? scale : 1.0f;
+      float y[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        y[4 * q] = (v[2 * h + q][0] + b[2 * h + q].x) * s; y[4 * q + 1] = (v[2 * h + q][1] + b[2 * h + q].y) * s;
+        y[4 * q + 2] = (v[2 * h + q][2] + b[2 * h + q].z) * s; y[4 * q + 3] = (v[2 * h + q][3] + b[2 * h + q].w) * s;
+      }
+      store_half8<T>(out + (size_t)m * ldc + n0 + 32 * h, y);
     }
-    store_half16<T>(out + (size_t)m * ldc + n0, y);
   }
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
     float4 b, l; load_cols(n0, b, l); finish4n(0, m, n0, v, b, b, b);
   }
 };
 
-// Exact-erf GELU (hidden_act="gelu"): x * Phi(x) with Phi from the Abramowitz-Stegun 7.1.26
-// rational form of erfc (|abs error| <= 1.5e-7, far below the 16-bit rounding of the output);
-// the negative branch uses erfc directly, so there is no cancellation in the tail.
+// Exact-erf GELU (hidden_act="gelu"): gelu(x) = max(x, 0) - |x| Phi(-|x|), which covers both signs
+// without a select and has no cancellation in the tail.  log2 Phi(-a) is smooth and close to a
+// parabola, so a degree-6 polynomial on [0, 6] (weighted least squares on the error of a Phi(-a))
+// followed by one exp2 gives |abs error| <= 5e-7 in fp32 -- far below the 16-bit rounding of the
+// output -- for one transcendental instead of the two (rcp, exp) of the Abramowitz-Stegun form;
+// a transcendental costs four plain VALU slots on this chip.  Beyond a = 6, a Phi(-a) < 6e-9 a.
 __device__ __forceinline__ float gelu_erf(float x) {
-  // u = |x| sqrt(log2(e) / 2), so that exp(-x^2 / 2) = exp2(-u^2); the 0.5 of Phi is folded into the
-  // coefficients; gelu(x) = max(x, 0) - |x| * erfc(|x| / sqrt 2) / 2 covers both signs without a select.
   const float ax = fabsf(x);
-  const float u = ax * 0.84932180028801904272f;
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.27273748087922245f, u, 1.0f));
-  float p = 0.5f * 1.061405429f;
-  p = __builtin_fmaf(p, t, 0.5f * -1.453152027f);
-  p = __builtin_fmaf(p, t, 0.5f * 1.421413741f);
-  p = __builtin_fmaf(p, t, 0.5f * -0.284496736f);
-  p = __builtin_fmaf(p, t, 0.5f * 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(-(u * u));
-  return __builtin_fmaf(-ax, (p * t) * e, fmaxf(x, 0.f));
+  const float a = fminf(ax, 6.0f);
+  float p = 3.275438741e-05f;
+  p = __builtin_fmaf(p, a, -7.609388156e-04f);
+  p = __builtin_fmaf(p, a, 8.037637648e-03f);
+  p = __builtin_fmaf(p, a, -5.332307151e-02f);
+  p = __builtin_fmaf(p, a, -4.588527004e-01f);
+  p = __builtin_fmaf(p, a, -1.151170468e+00f);
+  p = __builtin_fmaf(p, a, -9.999967080e-01f);
+  return __builtin_fmaf(-ax, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.f));
 }
 
 template <class T> struct EpiBiasGeluHalf {
@@ -109,20 +115,23 @@ template <class T> struct EpiBiasGeluHalf {
     *reinterpret_cast<Half4<T>*>(out + (size_t)m * ldc + n0) =
         to_half4<T>(gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y), gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w));
   }
-  __device__ __forceinline__ void finish16n(int, int m, int n0, const f32x4 (&v)[4], const float4 (&b)[4]) const {
-    if (m >= M || n0 >= N) return;
-    if (n0 + 16 > N || (ldc & 7)) {
+  __device__ __forceinline__ void finish8x2n(int, int m, int n0, const f32x4 (&v)[4], const float4 (&b)[4]) const {
+    if (m >= M) return;
+    if (n0 + 40 > N || (ldc & 7)) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) finish4n(0, m, n0 + 4 * q, v[q], b[q], b[q], b[q]);
+      for (int q = 0; q < 4; ++q) finish4n(0, m, n0 + 4 * (q & 1) + 32 * (q >> 1), v[q], b[q], b[q], b[q]);
       return;
     }
-    float y[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      y[4 * q] = gelu_erf(v[q][0] + b[q].x); y[4 * q + 1] = gelu_erf(v[q][1] + b[q].y);
-      y[4 * q + 2] = gelu_erf(v[q][2] + b[q].z); y[4 * q + 3] = gelu_erf(v[q][3] + b[q].w);
+    for (int h = 0; h < 2; ++h) {
+      float y[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        y[4 * q] = gelu_erf(v[2 * h + q][0] + b[2 * h + q].x); y[4 * q + 1] = gelu_erf(v[2 * h + q][1] + b[2 * h + q].y);
+        y[4 * q + 2] = gelu_erf(v[2 * h + q][2] + b[2 * h + q].z); y[4 * q + 3] = gelu_erf(v[2 * h + q][3] + b[2 * h + q].w);
+      }
+      store_half8<T>(out + (size_t)m * ldc + n0 + 32 * h, y);
     }
-    store_half16<T>(out + (size_t)m * ldc + n0, y);
   }
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
     float4 b, l; load_cols(n0, b, l); finish4n(0, m, n0, v, b, b, b);
@@ -287,6 +296,9 @@ constexpr int BM2 = 256, BN2 = 256;
 constexpr int OP_BYTES = 256 * BK * 2;        // 32 KiB per operand per stage
 constexpr int STAGE_BYTES = 2 * OP_BYTES;     // 64 KiB
 
+#ifdef COGAIM_STAMPS
+__device__ long long g_stamp_buf[256 * 12 * 4];
+#endif
 int g_gemm_band = -1;  // tile numbering of the persistent kernel: -1 = chosen per shape; tools/ may force a value
 
 #include "gemm_persistent.h"
@@ -377,6 +389,11 @@ int cogaim_gemm_patch_embed(const void* cols, const void* W, const float* bias, 
 
 // Tuning knob: 0 = 128x128 kernel for every problem; 1 = 256x256 kernel, one tile per workgroup;
 // 2 (default) = persistent 256x256 kernel.  1 and 2 apply to large problems only.
+#ifdef COGAIM_STAMPS
+int cogaim_debug_stamps(void* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamp_buf), sizeof(long long) * 256 * 12 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
 int cogaim_set_gemm_algo(int algo) {
   if (algo >= 200) { g_gemm_band = algo == 299 ? -1 : algo - 200; return COGAIM_OK; }   // tools/gemm_bench.py only
   if (algo >= 100) { g_gemm_diag = 1; g_gemm_algo = algo - 100; return COGAIM_OK; }   // tools/gemm_bench.py only

@@ -16,7 +16,7 @@
 //
 // DMA order within a K-tile, 2 pieces (1 KiB each) per wave per phase:
 //   phase 0: A rows first needed by phase 0 ("A-early", row mod 128 < 64)
-//   phase 1: W rows of phases 0 and 3      ("W-early", row mod 64 < 32, or row mod 16 < 8 when interleaved)
+//   phase 1: W rows of phases 0 and 3      ("W-early", row mod 64 < 32)
 //   phase 2: W rows of phases 1 and 2      ("W-late")
 //   phase 3: A rows of phases 2 and 3      ("A-late")
 // A piece is read two phases after the wait that retired it at the earliest, always behind a
@@ -29,10 +29,11 @@
 #pragma once
 
 // LDS chunk swizzles (row -> XOR on the 16-B chunk index, 0..7).  A fragments read rows fr, fr+16, ...;
-// W fragments read rows 16*(fr>>2) + 4*ni + (fr&3) (so that a lane ends up owning 16 adjacent output
-// columns), which needs a different function to stay bank-conflict free.
+// interleaved W fragments read rows 8*(fr>>2) + (fr&3) + 4*(ni&1) + 32*(ni>>1) (so that a lane ends up
+// owning two runs of 8 adjacent output columns), which needs a different function to stay bank-conflict
+// free; it ignores the two row bits that ni moves.
 __device__ __forceinline__ int swz_a(int row) { return (row >> 1) & 7; }
-__device__ __forceinline__ int swz_w(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
+__device__ __forceinline__ int swz_w(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
 
 struct PersistSched {
   int tiles_m;        // row tiles of one problem
@@ -62,9 +63,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
   using H = Half<T>;
   using v8 = typename H::v8;
-  // WIDE: W fragment rows are interleaved so that a lane owns 16 adjacent output columns (16-bit
-  // outputs: two 16-B stores per row instead of four 8-B ones).  fp32 outputs keep 4 columns per
-  // lane and fragment, which makes every store instruction cover 64 contiguous bytes per row.
+  // WIDE: W fragment rows are interleaved so that a lane owns output columns [8 fq, 8 fq + 8) and
+  // [32 + 8 fq, 32 + 8 fq + 8) of its wave's 64 (16-bit outputs: two 16-B stores per row, each of which
+  // the four lanes of a row make 64 contiguous bytes).  fp32 outputs keep 4 columns per lane and
+  // fragment, which makes every store instruction cover 64 contiguous bytes per row as well.
   constexpr bool WIDE = SWAP && Epi::kWide;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,13 +97,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
     const int e = 2 * wave + u;                         // 0..15
     pAe[u] = e < 8 ? e : e + 8;                         // rows (p*8) mod 128 < 64
     pAl[u] = pAe[u] + 8;
-    if constexpr (WIDE) {
-      pWe[u] = 2 * e;                                   // rows (p*8) mod 16 < 8
-      pWl[u] = 2 * e + 1;
-    } else {
-      pWe[u] = (e >> 2) * 8 + (e & 3);                  // rows (p*8) mod 64 < 32
-      pWl[u] = pWe[u] + 4;
-    }
+    pWe[u] = (e >> 2) * 8 + (e & 3);                    // rows (p*8) mod 64 < 32
+    pWl[u] = pWe[u] + 4;
   }
   const T* sAe[2]; const T* sAl[2]; const T* sWe[2]; const T* sWl[2];
   int d_item = 0, d_kt = 0, d_kt1 = 0;                  // DMA cursor
@@ -142,8 +139,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
   const int wr = wave >> 2, wc = wave & 3;
   const int fr = lane & 15, fq = lane >> 4;
   const int c0 = (fq ^ swz_a(fr)) << 4;                               // A k-chunk of k32 step 0; step 1 is c0 ^ 64
-  const int wrow = WIDE ? 16 * (fr >> 2) + (fr & 3) : fr;                // W row of this lane within the wave's 64
-  constexpr int W_NI_STRIDE = WIDE ? 4 * 128 : 16 * 128;                 // bytes between the rows of fragments ni, ni+1
+  const int wrow = WIDE ? 8 * (fr >> 2) + (fr & 3) : fr;                 // W row of this lane within the wave's 64
+  constexpr int W_NH_STRIDE = 32 * 128;                                  // bytes between the rows of fragments ni, ni+2
+  constexpr int W_NJ_STRIDE = WIDE ? 4 * 128 : 16 * 128;                 // ... and of fragments ni, ni+1
   const int cw0 = (fq ^ (WIDE ? swz_w(wrow) : swz_a(wrow))) << 4;
   const char* const a_base = smem + (wr * 128 + fr) * 128;               // + mi*2048
   const char* const w_base = smem + OP_BYTES + (wc * 64 + wrow) * 128;   // + ni*W_NI_STRIDE
@@ -162,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
 #define LOAD_W(dst_, nh_)                                                                            \
   _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                   \
   _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                   \
-    dst_[s_][j_] = *reinterpret_cast<const v8*>(w_base + boff + ((nh_) * 2 + j_) * W_NI_STRIDE + (s_ ? (cw0 ^ 64) : cw0))
+    dst_[s_][j_] = *reinterpret_cast<const v8*>(w_base + boff + (nh_) * W_NH_STRIDE + j_ * W_NJ_STRIDE + (s_ ? (cw0 ^ 64) : cw0))
 #define MATH(af_, wf_, mh_, nh_)                                                                     \
   do {                                                                                               \
     __builtin_amdgcn_s_setprio(1);                                                                   \
@@ -195,7 +193,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifdef COGAIM_STAMPS
+    if (tid == 0 && j < 12) g_stamp_buf[(bid * 12 + j) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int kt = it.kt0; kt < it.kt1; ++kt, ++flat) {
+#ifdef COGAIM_STAMPS
+      if (tid == 0 && j < 12 && kt == it.kt0 + 1) g_stamp_buf[(bid * 12 + j) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
       const int st = flat & 1;
       const int boff = st * STAGE_BYTES;
       const bool more = (DIAG == 1) ? false : d_valid;       // wave-uniform
@@ -226,6 +230,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
       BARRIER();
     }
 
+#ifdef COGAIM_STAMPS
+    if (tid == 0 && j < 12) g_stamp_buf[(bid * 12 + j) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int z = it.tile / sc.tiles_per_z, lt = it.tile - z * sc.tiles_per_z;
     int tm, tn; tile_coords(sc, lt, tm, tn);
     if (it.slice < 0) {
@@ -234,9 +241,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
       if constexpr (WIDE) {
         float4 cb[4], cl;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) epi.load_cols(n_base + 16 * fq + 4 * q, cb[q], cl);
+        for (int q = 0; q < 4; ++q) epi.load_cols(n_base + 8 * fq + 4 * (q & 1) + 32 * (q >> 1), cb[q], cl);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) epi.finish16n(z, m_base + 16 * i + fr, n_base + 16 * fq, acc[i], cb);
+        for (int i = 0; i < 8; ++i) epi.finish8x2n(z, m_base + 16 * i + fr, n_base + 8 * fq, acc[i], cb);
       } else if constexpr (SWAP) {
         float4 cb[4], cl[4];
 #pragma unroll
@@ -276,6 +283,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
         for (int jj = 0; jj < 4; ++jj)
           out[(size_t)(i * 4 + jj) * 512] = make_float4(acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]);
     }
+#ifdef COGAIM_STAMPS
+    if (lane == 0 && j < 12)   // slowest wave
+      atomicMax(reinterpret_cast<unsigned long long*>(&g_stamp_buf[(bid * 12 + j) * 4 + 3]),
+                (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
   }
   if (wr == 0) BARRIER();          // match the extra barrier of the trailing group
 
@@ -306,7 +318,7 @@ __global__ __launch_bounds__(512) void gemm256p_fixup_kernel(Epi epi, PersistSch
   const f32x4 v{a.x, a.y, a.z, a.w};
   const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, fq = lane >> 4;
   const int m_base = tm * BM2 + wr * 128, n_base = tn * BN2 + wc * 64;
-  if constexpr (WIDE) epi.store4n(z, m_base + 16 * i + fr, n_base + 16 * fq + 4 * jj, v);
+  if constexpr (WIDE) epi.store4n(z, m_base + 16 * i + fr, n_base + 8 * fq + 4 * (jj & 1) + 32 * (jj >> 1), v);
   else if constexpr (SWAP) epi.store4n(z, m_base + 16 * i + fr, n_base + 16 * jj + 4 * fq, v);
   else epi.store4m(z, m_base + 16 * i + 4 * fq, n_base + 16 * jj + fr, v);
 }
