@@ -47,14 +47,25 @@ __device__ __forceinline__ void store_half8(T* p, const float (&y)[8]) {   // 8 
   __builtin_nontemporal_store(*reinterpret_cast<const u4*>(h), reinterpret_cast<u4*>(p));
 }
 
-__device__ __forceinline__ float4 ldg4(const float* p, bool ok) {
+// Guarded 16-byte load without a branch: the address is moved to element 0 of the array when the guard
+// fails and the value zeroed afterwards, so that consecutive loads of an epilogue issue back to back
+// (a branch per load makes the compiler wait for each load before the next one is issued).
+__device__ __forceinline__ float4 ldg4(const float* base, size_t off, bool ok) {
+  float4 v = *reinterpret_cast<const float4*>(base + (ok ? off : 0));
+  if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+  return v;
+}
+
+// The branching form, for the residual tiles: their loads are issued in groups ahead of the stores
+// anyway, and skipping the out-of-range ones keeps edge tiles from touching memory they do not own.
+__device__ __forceinline__ float4 ldg4_guarded(const float* p, bool ok) {
   return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 template <class T> struct EpiBiasHalf {           // out16 = (acc + bias) [* scale for n < scale_cols]
   static constexpr bool kWide = true, kResidual = false;
   T* out; const float* bias; int ldc; int scale_cols; float scale; int M, N;
-  __device__ __forceinline__ void load_cols(int n0, float4& b, float4&) const { b = ldg4(bias + n0, n0 < N); }
+  __device__ __forceinline__ void load_cols(int n0, float4& b, float4&) const { b = ldg4(bias, n0, n0 < N); }
   __device__ __forceinline__ float4 load_res(int, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
   __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 b, float4, float4) const {
     if (m >= M || n0 >= N) return;
@@ -108,7 +119,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 template <class T> struct EpiBiasGeluHalf {
   static constexpr bool kWide = true, kResidual = false;
   T* out; const float* bias; int ldc; int M, N;
-  __device__ __forceinline__ void load_cols(int n0, float4& b, float4&) const { b = ldg4(bias + n0, n0 < N); }
+  __device__ __forceinline__ void load_cols(int n0, float4& b, float4&) const { b = ldg4(bias, n0, n0 < N); }
   __device__ __forceinline__ float4 load_res(int, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
   __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 b, float4, float4) const {
     if (m >= M || n0 >= N) return;
@@ -142,10 +153,10 @@ struct EpiResidualF32 {                            // x += (acc + bias) * layers
   static constexpr bool kWide = false, kResidual = true;
   float* x; const float* bias; const float* ls; int ldc; int M, N;
   __device__ __forceinline__ void load_cols(int n0, float4& b, float4& l) const {
-    b = ldg4(bias + n0, n0 < N); l = ldg4(ls + n0, n0 < N);
+    b = ldg4(bias, n0, n0 < N); l = ldg4(ls, n0, n0 < N);
   }
   __device__ __forceinline__ float4 load_res(int, int m, int n0) const {
-    return ldg4(x + (size_t)m * ldc + n0, m < M && n0 < N);
+    return ldg4_guarded(x + (size_t)m * ldc + n0, m < M && n0 < N);
   }
   __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 b, float4 l, float4 r) const {
     if (m >= M || n0 >= N) return;
@@ -175,10 +186,10 @@ struct EpiStoreF32 {                               // batched plain fp32 store (
 struct EpiPatchEmbed {                             // token row b*T+1+p = acc + bias + pos[1+p]
   static constexpr bool kWide = false, kResidual = true;
   float* x; const float* bias; const float* pos; int D; int P; int M;   // P patches per image
-  __device__ __forceinline__ void load_cols(int n0, float4& b, float4&) const { b = ldg4(bias + n0, n0 < D); }
+  __device__ __forceinline__ void load_cols(int n0, float4& b, float4&) const { b = ldg4(bias, n0, n0 < D); }
   __device__ __forceinline__ float4 load_res(int, int m, int n0) const {
     const int p = m % P;
-    return ldg4(pos + (size_t)(1 + p) * D + n0, m < M && n0 < D);
+    return ldg4_guarded(pos + (size_t)(1 + p) * D + n0, m < M && n0 < D);
   }
   __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 bi, float4, float4 po) const {
     if (m >= M || n0 >= D) return;

@@ -146,6 +146,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
   const char* const a_base = smem + (wr * 128 + fr) * 128;               // + mi*2048
   const char* const w_base = smem + OP_BYTES + (wc * 64 + wrow) * 128;   // + ni*W_NI_STRIDE
 
+  // Re-defines a loaded float4 through an empty asm.  With an LDS-DMA in flight the compiler turns every
+  // wait for an ordinary load into vmcnt(0), and it repeats that wait in every later basic block that
+  // uses the value: behind a store that makes the block wait for the store's write acknowledgement.  One
+  // wait here, after which the values no longer count as loaded, keeps the epilogue's stores streaming.
+#define PIN_LOADED4(v_) asm volatile("" : "+v"((v_).x), "+v"((v_).y), "+v"((v_).z), "+v"((v_).w))
 #define WAIT_LOAD(n_) asm volatile("s_waitcnt vmcnt(" #n_ ") lgkmcnt(0)" ::: "memory")
 #define BARRIER()                                  \
   do {                                             \
@@ -242,6 +247,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
         float4 cb[4], cl;
 #pragma unroll
         for (int q = 0; q < 4; ++q) epi.load_cols(n_base + 8 * fq + 4 * (q & 1) + 32 * (q >> 1), cb[q], cl);
+        PIN_LOADED4(cb[0]); PIN_LOADED4(cb[1]); PIN_LOADED4(cb[2]); PIN_LOADED4(cb[3]);
 #pragma unroll
         for (int i = 0; i < 8; ++i) epi.finish8x2n(z, m_base + 16 * i + fr, n_base + 8 * fq, acc[i], cb);
       } else if constexpr (SWAP) {
@@ -293,6 +299,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
 
 #undef DMA2
 #undef WAIT_LOAD
+#undef PIN_LOADED4
 #undef BARRIER
 #undef LOAD_A
 #undef LOAD_W

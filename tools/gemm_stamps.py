@@ -39,7 +39,12 @@ def run():
 
 for _ in range(3):
     run()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+run()
+e1.record()
 torch.cuda.synchronize()
+print(f"launch (kernel + fix-up): {e0.elapsed_time(e1) * 1e3:.1f} us")
 buf = np.zeros(256 * 12 * 4, dtype=np.int64)
 lib = ctypes.CDLL(_lib.LIB_PATH)
 lib.cogaim_debug_stamps.argtypes = [ctypes.c_void_p]
@@ -52,8 +57,13 @@ s -= t0
 items = int(os.environ.get("ITEMS", "8"))
 print("item: start(min/max over WGs)  first-K-tile  rest-of-mainloop  epilogue-issue   [us, mean over WGs]")
 for j in range(items):
-    st = s[:, j, 0]
-    print(f"{j}: start {st.min():7.2f}..{st.max():7.2f}  first {np.mean(s[:, j, 1] - s[:, j, 0]):6.2f}  "
-          f"rest {np.mean(s[:, j, 2] - s[:, j, 1]):6.2f}  epi {np.mean(s[:, j, 3] - s[:, j, 2]):6.2f}  "
-          f"end {s[:, j, 3].min():7.2f}..{s[:, j, 3].max():7.2f}")
+    w = s[s[:, j, 0] >= 0]                               # workgroups that have an item j
+    if not len(w):
+        break
+    st = w[:, j, 0]
+    print(f"{j}: ({len(w):3d} WGs) start {st.min():7.2f}..{st.max():7.2f}  first {np.mean(w[:, j, 1] - w[:, j, 0]):6.2f}  "
+          f"rest {np.mean(w[:, j, 2] - w[:, j, 1]):6.2f}  epi {np.mean(w[:, j, 3] - w[:, j, 2]):6.2f}  "
+          f"end {w[:, j, 3].min():7.2f}..{w[:, j, 3].max():7.2f}")
+last = s[:, :, 3].max(axis=1)
+print(f"last epilogue issued: min {last.min():.1f} max {last.max():.1f} us")
 print("WG 0, 1, 8, 100 starts:", [[round(float(v), 1) for v in s[b, :items, 0]] for b in (0, 1, 8, 100) if b < len(s)])

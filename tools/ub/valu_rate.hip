@@ -6,7 +6,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 #define REP8(x) x x x x x x x x
 template <int KIND>
-__global__ __launch_bounds__(512) void k(float* out, long long* cyc, int iters) {
+__global__ __launch_bounds__(768) void k(float* out, long long* cyc, int iters) {
   float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
   f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = p0 + 1.f, p5 = p1 + 1.f, p6 = p2 + 1.f, p7 = p3 + 1.f;
   const float c = 0.999f, d = 1e-3f;
@@ -38,6 +38,14 @@ __global__ __launch_bounds__(512) void k(float* out, long long* cyc, int iters) 
       REP8(asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n"
                         "v_pk_add_f32 %4, %4, %9\n v_pk_add_f32 %5, %5, %9\n v_pk_add_f32 %6, %6, %9\n v_pk_add_f32 %7, %7, %9"
                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pc), "v"(pd));)
+    } else if constexpr (KIND == 7) {   // 4 exp + 4 fma interleaved, independent chains
+      REP8(asm volatile("v_exp_f32 %0, %0\n v_fma_f32 %4, %4, %8, %9\n v_exp_f32 %1, %1\n v_fma_f32 %5, %5, %8, %9\n"
+                        "v_exp_f32 %2, %2\n v_fma_f32 %6, %6, %8, %9\n v_exp_f32 %3, %3\n v_fma_f32 %7, %7, %8, %9"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));)
+    } else if constexpr (KIND == 8) {   // 2 exp + 6 fma
+      REP8(asm volatile("v_exp_f32 %0, %0\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %5, %5, %8, %9\n"
+                        "v_exp_f32 %2, %2\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %7, %7, %8, %9"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));)
     } else {
       REP8(asm volatile("v_cvt_pk_f16_f32 %0, %0, %1\n v_cvt_pk_f16_f32 %1, %1, %2\n v_cvt_pk_f16_f32 %2, %2, %3\n v_cvt_pk_f16_f32 %3, %3, %4\n"
                         "v_cvt_pk_f16_f32 %4, %4, %5\n v_cvt_pk_f16_f32 %5, %5, %6\n v_cvt_pk_f16_f32 %6, %6, %7\n v_cvt_pk_f16_f32 %7, %7, %0"
@@ -52,7 +60,7 @@ __global__ __launch_bounds__(512) void k(float* out, long long* cyc, int iters) 
 template <int KIND> void run(const char* name) {
   float* out; long long* cyc;
   hipMalloc(&out, 512 * 4 * 4); hipMalloc(&cyc, 64);
-  for (int threads : {256, 512}) {
+  for (int threads : {256, 512, 768}) {
     const int iters = 1000;
     k<KIND><<<1, threads>>>(out, cyc, iters);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -70,6 +78,6 @@ template <int KIND> void run(const char* name) {
 
 int main() {
   run<0>("v_fma_f32"); run<1>("v_pk_fma_f32"); run<2>("v_exp_f32"); run<3>("v_rcp_f32"); run<4>("v_med3_f32");
-  run<5>("v_pk_mul/add"); run<6>("v_cvt_pk_f16");
+  run<5>("v_pk_mul/add"); run<6>("v_cvt_pk_f16"); run<7>("4exp+4fma"); run<8>("2exp+6fma");
   return 0;
 }
