@@ -56,14 +56,9 @@ __device__ __forceinline__ float4 ldg4(const float* base, size_t off, bool ok) {
   return v;
 }
 
-// The branching form, for the residual tiles: their loads are issued in groups ahead of the stores
-// anyway, and skipping the out-of-range ones keeps edge tiles from touching memory they do not own.
-__device__ __forceinline__ float4 ldg4_guarded(const float* p, bool ok) {
-  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
 template <class T> struct EpiBiasHalf {           // out16 = (acc + bias) [* scale for n < scale_cols]
   static constexpr bool kWide = true, kResidual = false;
+  static constexpr int kColVecs = 1;   // per-column vectors load_cols fills: 0 none, 1 bias, 2 bias and scale
   T* out; const float* bias; int ldc; int scale_cols; float scale; int M, N;
   __device__ __forceinline__ void load_cols(int n0, float4& b, float4&) const { b = ldg4(bias, n0, n0 < N); }
   __device__ __forceinline__ float4 load_res(int, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -118,6 +113,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 
 template <class T> struct EpiBiasGeluHalf {
   static constexpr bool kWide = true, kResidual = false;
+  static constexpr int kColVecs = 1;   // per-column vectors load_cols fills: 0 none, 1 bias, 2 bias and scale
   T* out; const float* bias; int ldc; int M, N;
   __device__ __forceinline__ void load_cols(int n0, float4& b, float4&) const { b = ldg4(bias, n0, n0 < N); }
   __device__ __forceinline__ float4 load_res(int, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -151,12 +147,13 @@ template <class T> struct EpiBiasGeluHalf {
 
 struct EpiResidualF32 {                            // x += (acc + bias) * layerscale   (in place)
   static constexpr bool kWide = false, kResidual = true;
+  static constexpr int kColVecs = 2;   // per-column vectors load_cols fills: 0 none, 1 bias, 2 bias and scale
   float* x; const float* bias; const float* ls; int ldc; int M, N;
   __device__ __forceinline__ void load_cols(int n0, float4& b, float4& l) const {
     b = ldg4(bias, n0, n0 < N); l = ldg4(ls, n0, n0 < N);
   }
   __device__ __forceinline__ float4 load_res(int, int m, int n0) const {
-    return ldg4_guarded(x + (size_t)m * ldc + n0, m < M && n0 < N);
+    return ldg4(x, (size_t)m * ldc + n0, m < M && n0 < N);
   }
   __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 b, float4 l, float4 r) const {
     if (m >= M || n0 >= N) return;
@@ -171,6 +168,7 @@ struct EpiResidualF32 {                            // x += (acc + bias) * layers
 
 struct EpiStoreF32 {                               // batched plain fp32 store (focal scores)
   static constexpr bool kWide = false, kResidual = false;
+  static constexpr int kColVecs = 0;   // per-column vectors load_cols fills: 0 none, 1 bias, 2 bias and scale
   float* out; int ldc; long long strideC; int M, N;
   __device__ __forceinline__ void load_cols(int, float4&, float4&) const {}
   __device__ __forceinline__ float4 load_res(int, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -185,11 +183,12 @@ struct EpiStoreF32 {                               // batched plain fp32 store (
 
 struct EpiPatchEmbed {                             // token row b*T+1+p = acc + bias + pos[1+p]
   static constexpr bool kWide = false, kResidual = true;
+  static constexpr int kColVecs = 1;   // per-column vectors load_cols fills: 0 none, 1 bias, 2 bias and scale
   float* x; const float* bias; const float* pos; int D; int P; int M;   // P patches per image
   __device__ __forceinline__ void load_cols(int n0, float4& b, float4&) const { b = ldg4(bias, n0, n0 < D); }
   __device__ __forceinline__ float4 load_res(int, int m, int n0) const {
     const int p = m % P;
-    return ldg4_guarded(pos + (size_t)(1 + p) * D + n0, m < M && n0 < D);
+    return ldg4(pos, (size_t)(1 + p) * D + n0, m < M && n0 < D);
   }
   __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 bi, float4, float4 po) const {
     if (m >= M || n0 >= D) return;

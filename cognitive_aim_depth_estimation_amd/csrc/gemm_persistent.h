@@ -251,23 +251,35 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
 #pragma unroll
         for (int i = 0; i < 8; ++i) epi.finish8x2n(z, m_base + 16 * i + fr, n_base + 8 * fq, acc[i], cb);
       } else if constexpr (SWAP) {
+        constexpr int RG = 1;   // fragment rows per group of residual loads (2 spills registers)
         float4 cb[4], cl[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) epi.load_cols(n_base + 16 * jj + 4 * fq, cb[jj], cl[jj]);
 #pragma unroll
-        for (int part = 0; part < 4; ++part) {        // 8 residual loads in flight per lane (register budget)
-          float4 xr[2][4];
+        for (int jj = 0; jj < 4; ++jj) {
+          if constexpr (Epi::kColVecs >= 1) PIN_LOADED4(cb[jj]);
+          if constexpr (Epi::kColVecs >= 2) PIN_LOADED4(cl[jj]);
+        }
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+        for (int part = 0; part < 8 / RG; ++part) {   // 4 RG residual loads in flight per lane (register budget)
+          float4 xr[RG][4];
+#pragma unroll
+          for (int i = 0; i < RG; ++i)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
               xr[i][jj] = Epi::kResidual
-                  ? epi.load_res(z, m_base + 16 * (2 * part + i) + fr, n_base + 16 * jj + 4 * fq) : cb[jj];
+                  ? epi.load_res(z, m_base + 16 * (RG * part + i) + fr, n_base + 16 * jj + 4 * fq) : cb[jj];
+          if constexpr (Epi::kResidual) {             // one wait per group instead of one per store
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < RG; ++i)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) PIN_LOADED4(xr[i][jj]);
+          }
+#pragma unroll
+          for (int i = 0; i < RG; ++i)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
-              epi.finish4n(z, m_base + 16 * (2 * part + i) + fr, n_base + 16 * jj + 4 * fq, acc[2 * part + i][jj],
+              epi.finish4n(z, m_base + 16 * (RG * part + i) + fr, n_base + 16 * jj + 4 * fq, acc[RG * part + i][jj],
                            cb[jj], cl[jj], xr[i][jj]);
         }
       } else {
