@@ -130,6 +130,89 @@ __global__ __launch_bounds__(256) void focal_colsum_kernel(const float* __restri
   }
 }
 
+// The STATS form of the kernel above for N <= 256 * NCH, with every score read ONCE: a wave keeps four whole rows
+// in registers (NCH float4 per lane and row), takes their maxima and exp2 sums from there, and adds the
+// normalised rows into per-lane column sums; the four waves' column sums meet in LDS.  Row order per column is
+// fixed (wave by wave, rows ascending inside a wave), so the result does not depend on timing.
+template <int NCH>
+__global__ __launch_bounds__(256) void focal_stats_colsum_rows_kernel(const float* __restrict__ S, int ldS,
+                                                                      long long strideS, float* __restrict__ rmax,
+                                                                      float* __restrict__ rinv, float* __restrict__ part,
+                                                                      int N, int nblk) {
+  __shared__ float4 red[4][NCH * 64];
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blk * CS_ROWS;
+  const float* Sb = S + b * strideS;
+  float4 cs[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) cs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int g = 0; g < CS_ROWS / 16; ++g) {
+    float4 v[4][NCH];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = r0 + wave + 4 * (4 * g + k);
+      ok[k] = row < N;
+      const float* sr = Sb + (size_t)(ok[k] ? row : N - 1) * ldS;   // rows are 16-B aligned (ldS % 4 == 0)
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        const int c = lane * 4 + 256 * j;
+        v[k][j] = c < N ? *reinterpret_cast<const float4*>(sr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c + 1 >= N) v[k][j].y = -INFINITY;                       // also covers c >= N: the whole chunk
+        if (c + 2 >= N) v[k][j].z = -INFINITY;
+        if (c + 3 >= N) v[k][j].w = -INFINITY;
+        if (c >= N) v[k][j].x = -INFINITY;
+      }
+    }
+    float mx[4], sum[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mx[k] = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j)
+        mx[k] = fmaxf(fmaxf(mx[k], fmaxf(v[k][j].x, v[k][j].y)), fmaxf(v[k][j].z, v[k][j].w));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o, 64));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sum[k] = 0.f;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        v[k][j].x = __builtin_amdgcn_exp2f(v[k][j].x - mx[k]); v[k][j].y = __builtin_amdgcn_exp2f(v[k][j].y - mx[k]);
+        v[k][j].z = __builtin_amdgcn_exp2f(v[k][j].z - mx[k]); v[k][j].w = __builtin_amdgcn_exp2f(v[k][j].w - mx[k]);
+        sum[k] += (v[k][j].x + v[k][j].y) + (v[k][j].z + v[k][j].w);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sum[k] += __shfl_xor(sum[k], o, 64);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float inv = ok[k] ? 1.0f / sum[k] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        cs[j].x += v[k][j].x * inv; cs[j].y += v[k][j].y * inv; cs[j].z += v[k][j].z * inv; cs[j].w += v[k][j].w * inv;
+      }
+      if (lane == 0 && ok[k]) {
+        const int row = r0 + wave + 4 * (4 * g + k);
+        rmax[(size_t)b * N + row] = mx[k]; rinv[(size_t)b * N + row] = inv;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) red[wave][j * 64 + lane] = cs[j];
+  __syncthreads();
+  const float* r = reinterpret_cast<const float*>(&red[0][0]);
+  for (int c = tid; c < N; c += 256)
+    part[((size_t)b * nblk + blk) * N + c] =
+        (r[c] + r[NCH * 256 + c]) + (r[2 * NCH * 256 + c] + r[3 * NCH * 256 + c]);
+}
+
 // colsum[b][c] = sum_blk part[b][blk][c]      (wide grid: one thread per column)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nblk,
                                                               float* __restrict__ out, int N) {
@@ -278,8 +361,12 @@ int cogaim_focal_softmax_stats_colsum(const float* S, int ldS, long long strideS
                                       int B, int N, void* stream) {
   if (B <= 0 || N <= 0 || ldS < N) return COGAIM_EINVAL;
   const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
-  hipLaunchKernelGGL(focal_colsum_kernel<true>, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, S, ldS, strideS, rmax,
-                     rinv, (const float*)nullptr, part, N, nblk);
+  if (N <= 1536 && !(ldS & 3))       // the 518-pixel grid (N = 1369) and smaller: rows fit in registers
+    hipLaunchKernelGGL(focal_stats_colsum_rows_kernel<6>, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, S, ldS,
+                       strideS, rmax, rinv, part, N, nblk);
+  else
+    hipLaunchKernelGGL(focal_colsum_kernel<true>, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, S, ldS, strideS,
+                       rmax, rinv, (const float*)nullptr, part, N, nblk);
   return COGAIM_LAUNCH_CHECK();
 }
 

@@ -46,6 +46,28 @@ __global__ __launch_bounds__(768) void k(float* out, long long* cyc, int iters) 
       REP8(asm volatile("v_exp_f32 %0, %0\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %5, %5, %8, %9\n"
                         "v_exp_f32 %2, %2\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %7, %7, %8, %9"
                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));)
+    } else if constexpr (KIND == 9) {
+      REP8(asm volatile("v_exp_f16_e32 %0, %0\n v_exp_f16_e32 %1, %1\n v_exp_f16_e32 %2, %2\n v_exp_f16_e32 %3, %3\n"
+                        "v_exp_f16_e32 %4, %4\n v_exp_f16_e32 %5, %5\n v_exp_f16_e32 %6, %6\n v_exp_f16_e32 %7, %7"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+    } else if constexpr (KIND == 10) {
+      REP8(asm volatile("v_exp_f16_sdwa %0, %0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n"
+                        "v_exp_f16_sdwa %1, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n"
+                        "v_exp_f16_sdwa %2, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n"
+                        "v_exp_f16_sdwa %3, %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n"
+                        "v_exp_f16_sdwa %4, %4 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\n"
+                        "v_exp_f16_sdwa %5, %5 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\n"
+                        "v_exp_f16_sdwa %6, %6 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\n"
+                        "v_exp_f16_sdwa %7, %7 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+    } else if constexpr (KIND == 11) {
+      REP8(asm volatile("v_dot2_f32_f16 %0, %8, %9, %0\n v_dot2_f32_f16 %1, %8, %9, %1\n v_dot2_f32_f16 %2, %8, %9, %2\n v_dot2_f32_f16 %3, %8, %9, %3\n"
+                        "v_dot2_f32_f16 %4, %8, %9, %4\n v_dot2_f32_f16 %5, %8, %9, %5\n v_dot2_f32_f16 %6, %8, %9, %6\n v_dot2_f32_f16 %7, %8, %9, %7"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));)
+    } else if constexpr (KIND == 12) {
+      REP8(asm volatile("v_max3_f32 %0, %0, %8, %9\n v_max3_f32 %1, %1, %8, %9\n v_max3_f32 %2, %2, %8, %9\n v_max3_f32 %3, %3, %8, %9\n"
+                        "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %9\n v_add_f32 %7, %7, %9"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));)
     } else {
       REP8(asm volatile("v_cvt_pk_f16_f32 %0, %0, %1\n v_cvt_pk_f16_f32 %1, %1, %2\n v_cvt_pk_f16_f32 %2, %2, %3\n v_cvt_pk_f16_f32 %3, %3, %4\n"
                         "v_cvt_pk_f16_f32 %4, %4, %5\n v_cvt_pk_f16_f32 %5, %5, %6\n v_cvt_pk_f16_f32 %6, %6, %7\n v_cvt_pk_f16_f32 %7, %7, %0"
@@ -79,5 +101,6 @@ template <int KIND> void run(const char* name) {
 int main() {
   run<0>("v_fma_f32"); run<1>("v_pk_fma_f32"); run<2>("v_exp_f32"); run<3>("v_rcp_f32"); run<4>("v_med3_f32");
   run<5>("v_pk_mul/add"); run<6>("v_cvt_pk_f16"); run<7>("4exp+4fma"); run<8>("2exp+6fma");
+  run<9>("v_exp_f16"); run<10>("v_exp_f16_sdwa"); run<11>("v_dot2_f32_f16"); run<12>("4max3+4add");
   return 0;
 }
