@@ -309,6 +309,7 @@ constexpr int STAGE_BYTES = 2 * OP_BYTES;     // 64 KiB
 #ifdef COGAIM_STAMPS
 __device__ long long g_stamp_buf[256 * 12 * 4];
 #endif
+int g_gemm_slice_cap = 0;
 int g_gemm_band = -1;  // tile numbering of the persistent kernel: -1 = chosen per shape; tools/ may force a value
 
 #include "gemm_persistent.h"
@@ -405,6 +406,7 @@ int cogaim_debug_stamps(void* dst) {
 }
 #endif
 int cogaim_set_gemm_algo(int algo) {
+  if (algo >= 1000) { g_gemm_slice_cap = algo - 1000; return COGAIM_OK; }   // tools/gemm_bench.py only
   if (algo >= 200) { g_gemm_band = algo == 299 ? -1 : algo - 200; return COGAIM_OK; }   // tools/gemm_bench.py only
   if (algo >= 100) { g_gemm_diag = 1; g_gemm_algo = algo - 100; return COGAIM_OK; }   // tools/gemm_bench.py only
   if (algo < 0 || algo > 2) return COGAIM_EINVAL;

@@ -360,7 +360,10 @@ int launch_persistent(const GemmShape& g, const Epi& epi, int batch, hipStream_t
     sc.n_split = rem;
     int slices = lanes / rem;
     if (slices > nk) slices = nk;
-    if (slices > 8) slices = 8;          // more slices only lengthen the fix-up pass
+    // at least two K-tiles per slice and at most 8 slices: a slice costs a 256 KB partial store and a pass of the
+    // fix-up whatever its length (K = 768: 6 slices run 1% faster than 8 or 12)
+    const int cap = g_gemm_slice_cap > 0 ? g_gemm_slice_cap : (nk / 2 < 8 ? (nk / 2 > 1 ? nk / 2 : 1) : 8);
+    if (slices > cap) slices = cap;
     if (slices >= 2 && workspace && (long long)rem * slices * 32 * 512 * 16 <= workspace_bytes) sc.slices = slices;
   }
   sc.nblk_full = persistent ? lanes : sc.n_full;
