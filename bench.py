@@ -139,6 +139,10 @@ def main():
             dist.all_gather_into_tensor(gathered, torch.cat([d, c], dim=1))
         return d, c
 
+    # set-up, not warm-up: the model's first call of a batch shape launches eagerly and its second one records
+    # the HIP graph that every later call replays; both belong to model construction like any compile step
+    for _ in range(2):
+        step()
     for _ in range(args.warmup):
         step()
     if world > 1:
