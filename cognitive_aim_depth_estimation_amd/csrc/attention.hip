@@ -106,17 +106,25 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
 
     // S^T = K Q^T - m_run : s[kb][i] = S^T[key kb*32 + (i&3) + 8(i>>2) + 4hh][query ql], already relative
     // to the running maximum (the accumulator starts at -m_run, so no subtraction pass is needed)
+    // All eight K fragments are requested before the first MFMA and the two accumulator chains alternate: left to
+    // itself the compiler reads one fragment, waits for it, and issues one MFMA that depends on the previous one.
     f32x16 s[2];
+    v8 kf[2][4];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int r = kb * 32 + ql;
       const int sw = (r >> 1) & 7;
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const v8 kf = *reinterpret_cast<const v8*>(ks + r * 128 + (((2 * s4 + hh) ^ sw) << 4));
-        s[kb] = Hf::mfma32(kf, qf[s4], s4 == 0 ? negm : s[kb]);     // negm: 16 registers holding -m_run
-      }
+      for (int s4 = 0; s4 < 4; ++s4)
+        kf[kb][s4] = *reinterpret_cast<const v8*>(ks + r * 128 + (((2 * s4 + hh) ^ sw) << 4));
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        s[kb] = Hf::mfma32(kf[kb][s4], qf[s4], s4 == 0 ? negm : s[kb]);     // negm: 16 registers holding -m_run
+    __builtin_amdgcn_sched_barrier(0);
     if (kv0 + KV > Tn) {   // mask keys past the sequence end (last tile only)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
