@@ -68,6 +68,17 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
     vreg0 = *reinterpret_cast<const uint4*>(vbase + (row0 + key0) * ldqk + sc * 8);              \
     vreg1 = *reinterpret_cast<const uint4*>(vbase + (row0 + key1) * ldqk + sc * 8);              \
   }
+  // the same for a tile that lies wholly inside the sequence: two running pointers, V at a constant offset
+  // from K, no per-tile index arithmetic (the clamping form above costs ~20 vector instructions a tile)
+  const T* kp0 = kbase + (row0 + sr0) * ldqk + sc * 8;
+  const T* kp1 = kbase + (row0 + sr1) * ldqk + sc * 8;
+  const size_t tile_step = (size_t)KV * ldqk;
+#define LOAD_TILE_INSIDE()                                                                       \
+  {                                                                                              \
+    kreg0 = *reinterpret_cast<const uint4*>(kp0); kreg1 = *reinterpret_cast<const uint4*>(kp1);  \
+    vreg0 = *reinterpret_cast<const uint4*>(kp0 + D); vreg1 = *reinterpret_cast<const uint4*>(kp1 + D); \
+    kp0 += tile_step; kp1 += tile_step;                                                          \
+  }
 #define STORE_TILE(buf_)                                                                         \
   {                                                                                              \
     char* ks_ = smem + (buf_) * K_TILE;                                                          \
@@ -95,12 +106,13 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
   float m_run = 0.f, l_run = 0.f;
 
   const int nt = (Tn + KV - 1) / KV;
-  LOAD_TILE(0);
+  if (nt > 1) LOAD_TILE_INSIDE() else LOAD_TILE(0);
   STORE_TILE(0);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int kv0 = t * KV;
-    if (t + 1 < nt) LOAD_TILE(kv0 + KV);
+    if (t + 2 < nt) LOAD_TILE_INSIDE()            // only the last tile can reach past the sequence end
+    else if (t + 1 < nt) LOAD_TILE(kv0 + KV);
     const char* ks = smem + (t & 1) * K_TILE;
     const char* vs = smem + (2 + (t & 1)) * K_TILE;
 
@@ -119,11 +131,12 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
         kf[kb][s4] = *reinterpret_cast<const v8*>(ks + r * 128 + (((2 * s4 + hh) ^ sw) << 4));
     }
     __builtin_amdgcn_sched_barrier(0);
+    s[0] = Hf::mfma32(kf[0][0], qf[0], negm);                             // negm: 16 registers holding -m_run
+    s[1] = Hf::mfma32(kf[1][0], qf[0], negm);
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
+    for (int s4 = 1; s4 < 4; ++s4)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-        s[kb] = Hf::mfma32(kf[kb][s4], qf[s4], s4 == 0 ? negm : s[kb]);     // negm: 16 registers holding -m_run
+      for (int kb = 0; kb < 2; ++kb) s[kb] = Hf::mfma32(kf[kb][s4], qf[s4], s[kb]);
     __builtin_amdgcn_sched_barrier(0);
     if (kv0 + KV > Tn) {   // mask keys past the sequence end (last tile only)
 #pragma unroll
@@ -221,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
 }
 
 #undef LOAD_TILE
+#undef LOAD_TILE_INSIDE
 #undef STORE_TILE
 
 }  // namespace
