@@ -78,6 +78,59 @@ __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ fu
   }
 }
 
+
+// Heat map for display (reference demo.py:533-552), one workgroup per image: cube the attention weights, multiply
+// everything at or below their 70th percentile by 0.3, rescale to [0, 1], pad to the G x G grid with zeros.
+// The percentile is numpy's default ("linear"): the weights are sorted in LDS (bitonic, padded with +inf to a power
+// of two) and the two order statistics around 0.7 (N - 1) interpolated the way numpy's _lerp does.
+constexpr int HM_MAX = 6144;      // weights per image (74 x 74 = 5476 at 1036 pixels); sort buffer: next power of two
+__global__ __launch_bounds__(256) void heatmap_kernel(const float* __restrict__ attn, float* __restrict__ out, int N,
+                                                      int GG, int npad) {
+  __shared__ float val[HM_MAX], srt[8192];
+  __shared__ float red[4];
+  __shared__ float thr_s;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* ab = attn + (size_t)b * N;
+  for (int i = tid; i < npad; i += 256) {
+    float v = INFINITY;
+    if (i < N) { const float a = ab[i]; v = a * a * a; val[i] = v; }
+    srt[i] = v;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npad; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const float x = srt[i], y = srt[l];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) { srt[i] = y; srt[l] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  if (tid == 0) {
+    const double pos = 0.7 * (double)(N - 1);
+    const int lo = (int)pos, hi = lo + 1 < N ? lo + 1 : N - 1;
+    const float t = (float)(pos - (double)lo);
+    const float a = srt[lo], c = srt[hi], diff = c - a;
+    thr_s = t >= 0.5f ? c - diff * (1.0f - t) : a + diff * t;
+  }
+  __syncthreads();
+  const float thr = thr_s;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = tid; i < N; i += 256) {
+    float v = val[i];
+    v = v > thr ? v : v * 0.3f;
+    val[i] = v; mn = fminf(mn, v); mx = fmaxf(mx, v);
+  }
+  mx = block_max_256(mx, red);
+  mn = -block_max_256(-mn, red);
+  const float inv = 1.0f / (mx - mn + 1e-8f);
+  float* ob = out + (size_t)b * GG;
+  for (int i = tid; i < GG; i += 256) ob[i] = i < N ? (val[i] - mn) * inv : 0.f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -106,6 +159,16 @@ int cogaim_heads(const float* fused, int K, const float* wd, const float* bd, co
   if (B <= 0 || K <= 0) return COGAIM_EINVAL;
   hipLaunchKernelGGL(heads_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, fused, K, wd, bd, wc, bc, w2,
                      b2, depth, conf, B);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+// out[b][G*G] = display heat map of attn[b][N] (G = ceil(sqrt(N)); N <= 6144).
+int cogaim_heatmap_postprocess(const float* attn, float* out, int B, int N, int G, void* stream) {
+  if (B <= 0 || N <= 0 || N > HM_MAX || G <= 0 || (long long)G * G < N || (long long)(G - 1) * (G - 1) >= N)
+    return COGAIM_EINVAL;
+  int npad = 1;
+  while (npad < N) npad <<= 1;
+  hipLaunchKernelGGL(heatmap_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, attn, out, N, G * G, npad);
   return COGAIM_LAUNCH_CHECK();
 }
 

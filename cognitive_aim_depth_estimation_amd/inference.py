@@ -10,6 +10,7 @@ initialised ``torch.distributed`` group (one process per GPU) and the per-image
 """
 from __future__ import annotations
 
+import math
 import os
 import warnings
 from pathlib import Path
@@ -191,19 +192,21 @@ def exif_rows(exifs: Sequence[Optional[Dict]], camera_to_id: Dict[str, int]) -> 
             "iso": torch.tensor(iso, dtype=torch.float32), "camera_idx": torch.tensor(cam, dtype=torch.long)}
 
 
-def heatmap_postprocess(attn: np.ndarray) -> np.ndarray:
-    """reference demo.py:533-552: cube, damp everything at or below the 70th percentile by 0.3,
-    min-max normalise, reshape to the (padded) square grid."""
-    a = np.power(np.asarray(attn, dtype=np.float64).ravel(), 3)
-    thr = np.percentile(a, 70)
-    a = np.where(a > thr, a, a * 0.3)
-    a = (a - a.min()) / (a.max() - a.min() + 1e-8)
-    n = len(a)
-    g = int(np.sqrt(n))
-    if g * g != n:
-        g = int(np.ceil(np.sqrt(n)))
-        a = np.concatenate([a, np.zeros(g * g - n)])
-    return a.reshape(g, g)
+def heatmap_postprocess(attn: torch.Tensor) -> torch.Tensor:
+    """reference demo.py:533-552 for a whole batch on the device: cube, damp everything at or below the 70th
+    percentile by 0.3, min-max normalise, lay out on the (zero padded) square grid.  attn [B,N] on the GPU ->
+    fp32 [B,G,G] on the GPU."""
+    from ._lib import call, stream_ptr
+    a = attn.detach().to(torch.float32).contiguous()
+    if a.dim() == 1:
+        a = a[None]
+    B, N = a.shape
+    G = int(math.isqrt(N))
+    if G * G != N:
+        G += 1
+    out = torch.empty(B, G, G, device=a.device, dtype=torch.float32)
+    call("cogaim_heatmap_postprocess", a.data_ptr(), out.data_ptr(), B, N, G, stream_ptr())
+    return out
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -322,7 +325,7 @@ class CognitiveAimInference:
                     depth, conf = self.model(x, exif)
                 attn = self.model.get_attention_weights()
                 dc = torch.cat([depth, conf], dim=1).float().cpu()
-                attn_cpu = attn.float().cpu().numpy() if attn is not None else None
+                heat = heatmap_postprocess(attn).cpu().numpy() if (attn is not None and self.render) else None
                 for j, (i, xt, exif_raw, orig_size) in enumerate(chunk):
                     local[i - lo] = dc[j]
                     meta = {"image_path": paths[i], "original_size": orig_size,
@@ -335,7 +338,7 @@ class CognitiveAimInference:
                     results[i] = (float(dc[j, 0]), float(dc[j, 1]), meta)
                     if self.render:
                         self._save_prediction_image(paths[i], xt, float(dc[j, 0]), float(dc[j, 1]),
-                                                    None if attn_cpu is None else attn_cpu[j], instruction)
+                                                    None if heat is None else heat[j], instruction)
         self.model.synchronize()
         if world > 1:
             everyone = gather_shards(local.to(self.device), n).cpu()
@@ -347,8 +350,9 @@ class CognitiveAimInference:
                     results[i] = (None, None, {"error": "failed on a remote rank"})
         return results
 
-    def _save_prediction_image(self, image_path, image_tensor, depth_value, confidence_score, attention, instruction):
-        """Three-panel PNG of reference demo.py:471-600 (image | attention overlay | numbers)."""
+    def _save_prediction_image(self, image_path, image_tensor, depth_value, confidence_score, grid, instruction):
+        """Three-panel PNG of reference demo.py:471-600 (image | attention overlay | numbers); `grid` is the
+        image's post-processed G x G heat map (heatmap_postprocess) or None."""
         try:
             import matplotlib
             matplotlib.use("Agg")
@@ -369,8 +373,7 @@ class CognitiveAimInference:
         axes[0].set_title("Original Image", fontsize=14, fontweight="bold")
         axes[0].axis("off")
         axes[1].imshow(img)
-        if attention is not None:
-            grid = heatmap_postprocess(attention)
+        if grid is not None:
             h, w = img.shape[:2]
             resized = zoom(grid, (h / grid.shape[0], w / grid.shape[1]), order=1)
             im = axes[1].imshow(resized, cmap="plasma", alpha=0.6, interpolation="bilinear", vmin=0, vmax=1)

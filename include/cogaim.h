@@ -159,6 +159,12 @@ int cogaim_exif_prep(const long long* camera_idx, const float* focal_length, con
 int cogaim_heads(const float* fused, int K, const float* wd, const float* bd, const float* wc, const float* bc,
                  const float* w2, const float* b2, float* depth, float* conf, int B, void* stream);
 
+/* demo.py:533-552 (the attention map as it is drawn): per image, weights cubed, those at or below their 70th
+ * percentile (numpy's default linear interpolation) multiplied by 0.3, min-max rescaled with the reference's
+ * 1e-8 in the denominator, laid out on the G x G grid (G = ceil(sqrt(N)), zero padded when N is not a square).
+ * attn fp32 [B,N], out fp32 [B,G*G]; N <= 6144. */
+int cogaim_heatmap_postprocess(const float* attn, float* out, int B, int N, int G, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
