@@ -308,9 +308,15 @@ class CognitiveAimModel(nn.Module):
         focal = []
         for i in range(self.num_iterations):
             p = f"focal_stream.focal_streams.{i}."
+            # Row softmax of Q K^T ignores terms that are constant along a row, so
+            #   (X Wq^T + bq)(X Wk^T + bk)^T  ~  (X (Wq^T Wk) + bq^T Wk) X^T :
+            # ONE 768-wide projection Y = X M^T + v with M = Wk^T Wq, v = bq Wk (softmax scale and log2 e folded
+            # in), and the scores are Y X^T against the tokens themselves (src/model.py:192-200).
+            wq, wk = sd[p + "query_proj.weight"].float(), sd[p + "key_proj.weight"].float()
+            ss = LOG2E / math.sqrt(wq.shape[1] // 8)   # FocalStream.scale = sqrt(patch_dim // num_heads), heads = 8
             focal.append({
-                "wqk": torch.cat([sd[p + "query_proj.weight"], sd[p + "key_proj.weight"]], 0).to(tdt).contiguous(),
-                "bqk": torch.cat([sd[p + "query_proj.bias"], sd[p + "key_proj.bias"]], 0).float().contiguous(),
+                "wm": ((wk.t() @ wq) * ss).to(tdt).contiguous(),
+                "bv": ((sd[p + "query_proj.bias"].float() @ wk) * ss).contiguous(),
             })
         pk["focal"] = focal
         pk["f32"] = {k: v.float().contiguous() for k, v in sd.items()
@@ -434,8 +440,6 @@ class CognitiveAimModel(nn.Module):
         tstride = T * D
         pe, cb = self._table("pe", N, D), self._table("cbias", N)
         h, qk, S = ws["h"].data_ptr(), ws["qk"].data_ptr(), ws["big"].data_ptr()
-        esz = 2
-        sscale = LOG2E / math.sqrt(D // 8)             # FocalStream.scale = sqrt(patch_dim // num_heads), heads = 8
         I = self.num_iterations
         for i in range(I):
             f = pk["focal"][i]
@@ -443,10 +447,10 @@ class CognitiveAimModel(nn.Module):
             s_in = None if i == 0 else ws["scale"][i % 2].data_ptr()
             s_out = None if i == I - 1 else ws["scale"][(i + 1) % 2].data_ptr()
             call("cogaim_focal_prep", tok, tstride, s_in, ptr(pe), h, B, N, D, dt, st)
-            call("cogaim_gemm_bias_half", h, ptr(f["wqk"]), ptr(f["bqk"]), qk, B * N, 2 * D, D, D, D, 2 * D, D, sscale, dt,
+            # Y = X~ M^T + v into the first D columns' worth of the qk buffer, then S[b] = Y[b] X~[b]^T (log2 domain)
+            call("cogaim_gemm_bias_half", h, ptr(f["wm"]), ptr(f["bv"]), qk, B * N, D, D, D, D, D, 0, 1.0, dt,
                  ws["gemm_ws"].data_ptr(), ws["gemm_ws"].numel(), st)
-            call("cogaim_gemm_batched_f32", qk, qk + D * esz, S, N, N, D, 2 * D, 2 * D, ldS,
-                 N * 2 * D, N * 2 * D, N * ldS, B, dt, st)
+            call("cogaim_gemm_batched_f32", qk, h, S, N, N, D, D, D, ldS, N * D, N * D, N * ldS, B, dt, st)
             call("cogaim_focal_softmax_stats_colsum", S, ldS, N * ldS, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["part"]), B, N, st)
             call("cogaim_focal_attention_vector", ptr(ws["part"]), ptr(cb), ptr(ws["attn"]), ptr(ws["stats"]),
                  s_in, s_out, self.focus_strength, B, N, st)
