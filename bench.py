@@ -166,7 +166,7 @@ def main():
     value = world * B * args.steps / elapsed
     fpi = flops_per_image(args.size, args.iters)
     out = {
-        "metric": "images/sec @518x518 full_cognitive forward (depth+confidence)",
+        "metric": f"images/sec @{args.size}x{args.size} full_cognitive forward (depth+confidence)",
         "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic (randn images, demo-default EXIF, seeded random-init weights)",
