@@ -47,6 +47,36 @@ __device__ __forceinline__ void store_half8(T* p, const float (&y)[8]) {   // 8 
   __builtin_nontemporal_store(*reinterpret_cast<const u4*>(h), reinterpret_cast<u4*>(p));
 }
 
+// A row's two 8-column runs (16-bit, 16 B each, 64 B apart) written so that every store instruction covers whole
+// 128-byte lines: lanes fr and fr ^ 8 of a 16-lane row exchange one run each (DPP row_ror:8), after which the lanes
+// fr < 8 hold the first halves of rows fr and fr + 8 and the lanes fr >= 8 the second halves; the first
+// instruction then writes rows 0..7 of the fragment complete, the second rows 8..15.  `row` points at this lane's
+// own row and run 0; rows of a fragment are `ldc` elements apart.  Without the exchange each instruction leaves
+// 16 half-written lines behind.
+template <class T>
+__device__ __forceinline__ void store_half8x2_lines(T* row, long long ldc, const float (&y0)[8], const float (&y1)[8]) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  alignas(16) T h0[8], h1[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { h0[i] = (T)y0[i]; h1[i] = (T)y1[i]; }
+  const u4 r0 = *reinterpret_cast<const u4*>(h0), r1 = *reinterpret_cast<const u4*>(h1);
+  const bool low = (threadIdx.x & 8) == 0;              // fr < 8 (fr = lane & 15)
+  u4 give, got;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    give[i] = low ? r1[i] : r0[i];
+    got[i] = (unsigned)__builtin_amdgcn_mov_dpp((int)give[i], 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+  }
+  u4 first, second;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { first[i] = low ? r0[i] : got[i]; second[i] = low ? got[i] : r1[i]; }
+  // lane fr < 8: rows fr, fr + 8, bytes 0..63;  lane fr >= 8: rows fr - 8, fr, bytes 64..127
+  T* p_first = low ? row : row - 8 * ldc + 32;
+  T* p_second = low ? row + 8 * ldc : row + 32;
+  __builtin_nontemporal_store(first, reinterpret_cast<u4*>(p_first));
+  __builtin_nontemporal_store(second, reinterpret_cast<u4*>(p_second));
+}
+
 // Guarded 16-byte load without a branch: the address is moved to element 0 of the array when the guard
 // fails and the value zeroed afterwards, so that consecutive loads of an epilogue issue back to back
 // (a branch per load makes the compiler wait for each load before the next one is issued).
@@ -86,6 +116,21 @@ template <class T> struct EpiBiasHalf {           // out16 = (acc + bias) [* sca
       }
       store_half8<T>(out + (size_t)m * ldc + n0 + 32 * h, y);
     }
+  }
+  // the same for a tile that lies wholly inside the matrix (every lane of the wave takes part): whole-line stores
+  __device__ __forceinline__ bool lines_ok() const { return !(ldc & 7) && !(scale_cols & 7); }
+  __device__ __forceinline__ void finish8x2n_lines(int, int m, int n0, const f32x4 (&v)[4], const float4 (&b)[4]) const {
+    float y[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float s = n0 + 32 * h < scale_cols ? scale : 1.0f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        y[h][4 * q] = (v[2 * h + q][0] + b[2 * h + q].x) * s; y[h][4 * q + 1] = (v[2 * h + q][1] + b[2 * h + q].y) * s;
+        y[h][4 * q + 2] = (v[2 * h + q][2] + b[2 * h + q].z) * s; y[h][4 * q + 3] = (v[2 * h + q][3] + b[2 * h + q].w) * s;
+      }
+    }
+    store_half8x2_lines<T>(out + (size_t)m * ldc + n0, ldc, y[0], y[1]);
   }
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
     float4 b, l; load_cols(n0, b, l); finish4n(0, m, n0, v, b, b, b);
@@ -139,6 +184,18 @@ template <class T> struct EpiBiasGeluHalf {
       }
       store_half8<T>(out + (size_t)m * ldc + n0 + 32 * h, y);
     }
+  }
+  __device__ __forceinline__ bool lines_ok() const { return !(ldc & 7); }
+  __device__ __forceinline__ void finish8x2n_lines(int, int m, int n0, const f32x4 (&v)[4], const float4 (&b)[4]) const {
+    float y[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        y[h][4 * q] = gelu_erf(v[2 * h + q][0] + b[2 * h + q].x); y[h][4 * q + 1] = gelu_erf(v[2 * h + q][1] + b[2 * h + q].y);
+        y[h][4 * q + 2] = gelu_erf(v[2 * h + q][2] + b[2 * h + q].z); y[h][4 * q + 3] = gelu_erf(v[2 * h + q][3] + b[2 * h + q].w);
+      }
+    store_half8x2_lines<T>(out + (size_t)m * ldc + n0, ldc, y[0], y[1]);
   }
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
     float4 b, l; load_cols(n0, b, l); finish4n(0, m, n0, v, b, b, b);

@@ -248,8 +248,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) epi.load_cols(n_base + 8 * fq + 4 * (q & 1) + 32 * (q >> 1), cb[q], cl);
         PIN_LOADED4(cb[0]); PIN_LOADED4(cb[1]); PIN_LOADED4(cb[2]); PIN_LOADED4(cb[3]);
+        if ((tm + 1) * BM2 <= g.M && (tn + 1) * BN2 <= g.N && epi.lines_ok()) {   // wave-uniform
 #pragma unroll
-        for (int i = 0; i < 8; ++i) epi.finish8x2n(z, m_base + 16 * i + fr, n_base + 8 * fq, acc[i], cb);
+          for (int i = 0; i < 8; ++i) epi.finish8x2n_lines(z, m_base + 16 * i + fr, n_base + 8 * fq, acc[i], cb);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) epi.finish8x2n(z, m_base + 16 * i + fr, n_base + 8 * fq, acc[i], cb);
+        }
       } else if constexpr (SWAP) {
         constexpr int RG = 1;   // fragment rows per group of residual loads (2 spills registers)
         float4 cb[4], cl[4];
