@@ -7,7 +7,11 @@ config 4 is the same per-GPU batch on 8 GPUs, image-sharded, with one RCCL
 all-gather of the per-image [depth, confidence] pairs per step).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...            (starts the N rank processes itself; fails if fewer GPUs are visible)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+The headline operand type is bf16 (BASELINE config 2); fp16 is timed beside it (`by_dtype`), each with its
+parity against the CPU oracle on the same images.
 
 Prints ONE JSON line (rank 0).
 """
@@ -27,6 +31,7 @@ sys.path.insert(0, ROOT)
 MODULES = ["ambient_stream", "iterative_focal_stream", "exif_prior_database"]
 PEAK_TFLOPS = 2500.0       # dense bf16/fp16 MFMA peak of one MI355X
 HBM_PEAK_GBS = 8000.0
+STUB = os.environ.get("COGAIM_BENCH_STUB") == "1"      # CPU tests of the launcher path (no GPU, gloo)
 
 
 def flops_per_image(size: int, iters: int, layers: int = 12, D: int = 768, patch: int = 14) -> float:
@@ -79,6 +84,68 @@ def measured_traffic(entry):
     return int(k["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` outside a launcher: start the N rank processes (one per GPU, rendezvous on
+    127.0.0.1) before this process touches the GPU, pass rank 0's line through, return the worst exit code."""
+    import socket
+    import subprocess
+    if not STUB:
+        n_vis = torch.cuda.device_count()           # counts devices without initialising the GPU runtime
+        if n_vis < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} asked for, {n_vis} visible: refusing to report fewer\n")
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def stub_rank(args, world, rank):
+    """Launcher / collective path without a GPU (COGAIM_BENCH_STUB=1, gloo): the step is a fixed host delay.
+    Used by the CPU tests only; its line says so and carries no roofline."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    B = args.batch
+    gathered = torch.empty(world * B, 2) if world > 1 else None
+
+    def step():
+        time.sleep(0.002)
+        d = torch.full((B, 1), float(rank))
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, torch.cat([d, d], 1))
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        assert sorted(set(gathered[:, 0].tolist())) == [float(r) for r in range(world)]
+    if rank == 0:
+        print(json.dumps({"metric": "stub step (no GPU work)", "value": round(world * B * args.steps / elapsed, 2),
+                          "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,15 +154,30 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=518)
     ap.add_argument("--iters", type=int, default=3, help="focal refinement iterations")
-    ap.add_argument("--dtype", default=os.environ.get("COGAIM_DTYPE", "fp16"), choices=["fp16", "bf16"])
+    ap.add_argument("--dtype", default=os.environ.get("COGAIM_DTYPE", "bf16"), choices=["fp16", "bf16"],
+                    help="headline operand type (BASELINE config 2 is bf16); the other one is timed beside it")
     ap.add_argument("--streams", type=int, default=1, help="split each batch over this many HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-second-dtype", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks\n")
+        sys.exit(2)
+    if STUB:
+        return stub_rank(args, world, rank)
+    if torch.cuda.device_count() <= local_rank:
+        sys.stderr.write(f"bench.py: rank {rank} has no GPU (local rank {local_rank}, "
+                         f"{torch.cuda.device_count()} visible)\n")
+        sys.exit(2)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -105,9 +187,6 @@ def main():
     torch.cuda.set_device(dev)
 
     from cognitive_aim_depth_estimation_amd import create_model, _lib
-    cfg = {"cognitive_modules": MODULES, "compute_dtype": args.dtype,
-           "focal_config": {"num_iterations": args.iters, "focus_strength": 1.5}, "init_seed": 0}
-    model = create_model(cfg, {"num_cameras": 71}, device=dev)
     B = args.batch
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.randn(B, 3, args.size, args.size, device=dev, generator=g)
@@ -119,52 +198,61 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
     chunks = torch.arange(B).chunk(args.streams) if streams else None
 
-    def forward_batch():
-        if not streams:
-            return model(images, exif)
-        cur = torch.cuda.current_stream()
-        outs = []
-        for s_, idx in zip(streams, chunks):
-            s_.wait_stream(cur)
-            with torch.cuda.stream(s_):
-                lo, hi = int(idx[0]), int(idx[-1]) + 1
-                outs.append(model(images[lo:hi], {k: v[lo:hi] for k, v in exif.items()}))
-        for s_ in streams:
-            cur.wait_stream(s_)
-        return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+    def timed_run(dtype):
+        """W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides (max over ranks)."""
+        cfg = {"cognitive_modules": MODULES, "compute_dtype": dtype,
+               "focal_config": {"num_iterations": args.iters, "focus_strength": 1.5}, "init_seed": 0}
+        model = create_model(cfg, {"num_cameras": 71}, device=dev)
 
-    def step():
-        d, c = forward_batch()
-        if world > 1:   # per-image scalars of every shard to every rank (RCCL over xGMI)
-            dist.all_gather_into_tensor(gathered, torch.cat([d, c], dim=1))
-        return d, c
+        def forward_batch():
+            if not streams:
+                return model(images, exif)
+            cur = torch.cuda.current_stream()
+            outs = []
+            for s_, idx in zip(streams, chunks):
+                s_.wait_stream(cur)
+                with torch.cuda.stream(s_):
+                    lo, hi = int(idx[0]), int(idx[-1]) + 1
+                    outs.append(model(images[lo:hi], {k: v[lo:hi] for k, v in exif.items()}))
+            for s_ in streams:
+                cur.wait_stream(s_)
+            return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
 
-    # set-up, not warm-up: the model's first call of a batch shape launches eagerly and its second one records
-    # the HIP graph that every later call replays; both belong to model construction like any compile step
-    for _ in range(2):
-        step()
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        d, c = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    model.synchronize()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(d).all() and torch.isfinite(c).all()
+        def step():
+            d, c = forward_batch()
+            if world > 1:   # per-image scalars of every shard to every rank (RCCL over xGMI)
+                dist.all_gather_into_tensor(gathered, torch.cat([d, c], dim=1))
+            return d, c
 
+        # set-up, not warm-up: the model's first call of a batch shape launches eagerly and its second one records
+        # the HIP graph that every later call replays; both belong to model construction like any compile step
+        for _ in range(2):
+            step()
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            d, c = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        model.synchronize()
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert torch.isfinite(d).all() and torch.isfinite(c).all()
+        return model, d, c, elapsed
+
+    model, d, c, elapsed = timed_run(args.dtype)
     ms_per_step = 1000.0 * elapsed / args.steps
     value = world * B * args.steps / elapsed
     fpi = flops_per_image(args.size, args.iters)
+    frac = lambda v: round(v / world * fpi / 1e12 / PEAK_TFLOPS, 4)
     out = {
         "metric": f"images/sec @{args.size}x{args.size} full_cognitive forward (depth+confidence)",
         "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -174,10 +262,34 @@ def main():
                                f"ViT-B/14 12 layers + {args.iters} focal iterations",
                    "global_batch": world * B, "sharding": f"image-sharded dp{world}" if world > 1 else "single GPU"},
         "algorithmic_gflop_per_image": round(fpi / 1e9, 1),
-        "mfma_frac_end_to_end": round(value / world * fpi / 1e12 / PEAK_TFLOPS, 4),
+        "mfma_frac_end_to_end": frac(value),
+        "by_dtype": {args.dtype: {"value": round(value, 2), "ms_per_step": round(ms_per_step, 3),
+                                  "mfma_frac_end_to_end": frac(value)}},
     }
+    results = {args.dtype: (d, c)}
+
+    if not args.no_second_dtype:
+        # the other 16-bit operand type through the same steps and the same bracket, outside the headline's timed
+        # region: BASELINE names bf16; fp16 has the same MFMA rate, 3 more significand bits and 8 fewer exponent bits
+        other = "fp16" if args.dtype == "bf16" else "bf16"
+        del model
+        torch.cuda.empty_cache()
+        model, d2, c2, el2 = timed_run(other)
+        v2 = world * B * args.steps / el2
+        out["by_dtype"][other] = {"value": round(v2, 2), "ms_per_step": round(1000.0 * el2 / args.steps, 3),
+                                  "mfma_frac_end_to_end": frac(v2)}
+        results[other] = (d2, c2)
+        if other != args.dtype:      # the per-kernel profile below belongs to the headline type
+            del model
+            torch.cuda.empty_cache()
+            model = None
 
     if rank == 0 and not args.no_kernel_profile:
+        if model is None:
+            cfg = {"cognitive_modules": MODULES, "compute_dtype": args.dtype,
+                   "focal_config": {"num_iterations": args.iters, "focus_strength": 1.5}, "init_seed": 0}
+            model = create_model(cfg, {"num_cameras": 71}, device=dev)
+            model(images, exif)
         # per-kernel durations: HIP events on the launch stream around every C-ABI launch of 3 more steps
         _lib.PROFILE = []
         for _ in range(3):
@@ -202,23 +314,27 @@ def main():
         out["roofline"] = {"bound": "mfma", "kernel": f"{dname}{list(dshape)}", "avg_launch_ms": round(avg_ms, 4),
                            "achieved": round(achieved, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src}
+        out["mfma_frac_by_kernel"] = {f"{k[0]}{list(k[1])}": round(v[2] / (v[0] / v[1] * 1e-3) / 1e12 / PEAK_TFLOPS, 4)
+                                      for k, v in top if v[2]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cogaim_oracle as O
+        if model is None:
+            cfg = {"cognitive_modules": MODULES, "compute_dtype": args.dtype,
+                   "focal_config": {"num_iterations": args.iters, "focus_strength": 1.5}, "init_seed": 0}
+            model = create_model(cfg, {"num_cameras": 71}, device=dev)
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        nb, nf = 16, 4        # ~10-20 s of host work in total
+        nb, nf = min(16, B), min(4, B)        # ~10-20 s of host work in total
         xc = images[:nb].cpu()
         ec = {k: v[:nb].cpu() for k, v in exif.items()}
         with torch.no_grad():
-            O.forward(sd, xc[:1], {k: v[:1] for k, v in ec.items()})      # warm-up
+            O.forward(sd, xc[:1], {k: v[:1] for k, v in ec.items()}, focus_strength=1.5)      # warm-up
             t1 = time.perf_counter()
             d_ref, c_ref = O.forward(sd, xc, ec)
             t_dedup = time.perf_counter() - t1
             t1 = time.perf_counter()
             O.forward_faithful_schedule(sd, xc[:nf], {k: v[:nf] for k, v in ec.items()})
             t_faithful = time.perf_counter() - t1
-        rel = float(((d[:nb].cpu() - d_ref).abs() / d_ref.abs()).max())
-        relc = float(((c[:nb].cpu() - c_ref).abs() / c_ref.abs()).max())
         out["cpu_baseline"] = {
             "value": round(nb / t_dedup, 3), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{nb} images of the same batch through oracle/cogaim_oracle.py (PyTorch CPU fp32, "
@@ -227,7 +343,11 @@ def main():
             "faithful_schedule_note": f"{nf} images through the reference's as-executed schedule "
                                       "(2 backbone + 3 focal passes, Python position loop)",
             "host_cpus": os.cpu_count()}
-        out["parity_vs_oracle"] = {"depth_max_rel_err": rel, "conf_max_rel_err": relc, "images": nb}
+        for name, (dd, cc) in results.items():
+            rel = float(((dd[:nb].cpu() - d_ref).abs() / d_ref.abs()).max())
+            relc = float(((cc[:nb].cpu() - c_ref).abs() / c_ref.abs()).max())
+            out["by_dtype"][name]["parity_vs_oracle"] = {"depth_max_rel_err": rel, "conf_max_rel_err": relc, "images": nb}
+        out["parity_vs_oracle"] = out["by_dtype"][args.dtype]["parity_vs_oracle"]
 
     if rank == 0:
         print(json.dumps(out), flush=True)

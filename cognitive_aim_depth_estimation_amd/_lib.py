@@ -18,7 +18,6 @@ P, I, F, LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 # name -> argument types (all return int); mirrors include/cogaim.h
 SIGNATURES = {
     "cogaim_version": [],
-    "cogaim_allgather_f32": [P, P, LL, P, P],
     "cogaim_preprocess_rgb8": [P, I, I, LL, P, P, I, P, P, I, P, P, P, I, I, P],
     "cogaim_gemm_workspace_bytes": [],
     "cogaim_set_gemm_algo": [I],
@@ -26,10 +25,10 @@ SIGNATURES = {
     "cogaim_gemm_patch_embed": [P, P, P, P, P, I, I, I, I, I, P, LL, P],
     "cogaim_cls_row": [P, P, P, I, I, I, P],
     "cogaim_layernorm": [P, P, P, P, I, I, F, I, P],
-    "cogaim_gemm_bias_half": [P, P, P, P, I, I, I, I, I, I, I, F, I, P, LL, P],
+    "cogaim_gemm_bias_half": [P, P, P, P, I, I, I, I, I, I, I, F, I, P, LL, P, P],
     "cogaim_mhsa_qkv_fwd": [P, P, I, I, I, I, I, P],
     "cogaim_gemm_residual_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P, LL, P],
-    "cogaim_gemm_bias_gelu_half": [P, P, P, P, I, I, I, I, I, I, I, P, LL, P],
+    "cogaim_gemm_bias_gelu_half": [P, P, P, P, I, I, I, I, I, I, I, P, LL, P, P],
     "cogaim_focal_prep": [P, LL, P, P, P, I, I, I, I, P],
     "cogaim_gemm_batched_f32": [P, P, P, I, I, I, I, I, I, LL, LL, LL, I, I, P],
     "cogaim_focal_colsum_rows": [],
@@ -41,6 +40,8 @@ SIGNATURES = {
     "cogaim_weighted_tokens_rows": [],
     "cogaim_weighted_tokens": [P, LL, P, P, P, P, P, I, I, I, P],
     "cogaim_guided_attention": [P, P, P, I, I, F, F, P],
+    "cogaim_guided_attention_multi": [P, P, P, I, I, I, F, F, P],
+    "cogaim_weighted_tokens_multi": [P, LL, P, P, P, I, I, I, I, P],
     "cogaim_linear_f32": [P, I, P, P, P, P, I, I, I, I, I, P],
     "cogaim_exif_prep": [P, P, P, P, P, I, I, P, I, P, I, P, P],
     "cogaim_heads": [P, I, P, P, P, P, P, P, P, P, I, P],

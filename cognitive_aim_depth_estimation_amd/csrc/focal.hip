@@ -285,7 +285,8 @@ __global__ __launch_bounds__(256) void row_sum_kernel(const float* __restrict__ 
   if (tid == 0) usum[b] = t;
 }
 
-// part[b][chunk][d] = sum_{n in chunk} w[b][n] * (tok[b][n][d] * scale[b][n] + pe[n][d])   (scale, pe optional)
+// part[k][b][chunk][d] = sum_{n in chunk} w[k][b][n] * (tok[b][n][d] * scale[b][n] + pe[n][d])   (scale, pe optional;
+// k = blockIdx.z: several weight vectors per image share the tokens)
 constexpr int WT_ROWS = 32;
 __global__ __launch_bounds__(256) void weighted_tokens_partial_kernel(const float* __restrict__ tok,
                                                                       long long tok_stride_b,
@@ -296,6 +297,8 @@ __global__ __launch_bounds__(256) void weighted_tokens_partial_kernel(const floa
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int n0 = chunk * WT_ROWS, n1 = min(N, n0 + WT_ROWS);
   const float* tb = tok + b * tok_stride_b;
+  w += (size_t)blockIdx.z * gridDim.y * N;
+  part += (size_t)blockIdx.z * gridDim.y * nchunk * D;
   for (int c = threadIdx.x * 4; c < D; c += 1024) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int n = n0; n < n1; ++n) {
@@ -312,13 +315,14 @@ __global__ __launch_bounds__(256) void weighted_tokens_partial_kernel(const floa
   }
 }
 
-// guided[b][c] = softmax_c((0.7 mask[c] + 0.3 a[b][c]) / 0.05)     (model.py:1401-1409)
+// guided[k][b][c] = softmax_c((0.7 mask[k][c] + 0.3 a[b][c]) / 0.05)     (model.py:1401-1409; k = blockIdx.y)
 __global__ __launch_bounds__(256) void guided_attention_kernel(const float* __restrict__ a, const float* __restrict__ mask,
                                                                float* __restrict__ out, int N, float alpha, float inv_temp) {
   __shared__ float red[4];
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* ab = a + (size_t)b * N;
-  float* ob = out + (size_t)b * N;
+  float* ob = out + ((size_t)blockIdx.y * gridDim.x + b) * N;
+  mask += (size_t)blockIdx.y * N;
   float mx = -INFINITY;
   for (int c = tid; c < N; c += 256) {
     const float v = (alpha * mask[c] + (1.0f - alpha) * ab[c]) * inv_temp;
@@ -339,6 +343,9 @@ int grid_for(long long total) {
 }  // namespace
 
 extern "C" {
+
+int cogaim_guided_attention_multi(const float* a, const float* masks, float* out, int B, int N, int K, float alpha,
+                                  float temperature, void* stream);
 
 int cogaim_focal_colsum_rows() { return CS_ROWS; }
 
@@ -410,22 +417,43 @@ int cogaim_focal_reduce_u(const float* part, float* u, float* usum, int B, int N
 
 int cogaim_weighted_tokens_rows() { return WT_ROWS; }
 
-// workspace: fp32 [B * ceil(N / cogaim_weighted_tokens_rows()) * D]
-int cogaim_weighted_tokens(const float* tok, long long tok_stride_b, const float* scale, const float* pe, const float* w,
-                           float* out, float* workspace, int B, int N, int D, void* stream) {
-  if (B <= 0 || N <= 0 || D <= 0 || (D & 3) || (tok_stride_b & 3)) return COGAIM_EINVAL;
+// workspace: fp32 [K * B * ceil(N / cogaim_weighted_tokens_rows()) * D]; w [K, B, N] -> out [K, B, D]
+static int weighted_tokens_launch(const float* tok, long long tok_stride_b, const float* scale, const float* pe,
+                                  const float* w, float* out, float* workspace, int B, int N, int D, int K,
+                                  void* stream) {
+  if (B <= 0 || N <= 0 || D <= 0 || K <= 0 || K > 65535 || (long long)K * B > 65535 || (D & 3) || (tok_stride_b & 3) ||
+      !workspace)
+    return COGAIM_EINVAL;
   const int nchunk = (N + WT_ROWS - 1) / WT_ROWS;
-  hipLaunchKernelGGL(weighted_tokens_partial_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, tok,
+  hipLaunchKernelGGL(weighted_tokens_partial_kernel, dim3(nchunk, B, K), dim3(256), 0, (hipStream_t)stream, tok,
                      tok_stride_b, scale, pe, w, workspace, nchunk, N, D);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 255) / 256, B), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 255) / 256, K * B), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, nchunk, out, D);
   return COGAIM_LAUNCH_CHECK();
 }
 
+int cogaim_weighted_tokens(const float* tok, long long tok_stride_b, const float* scale, const float* pe, const float* w,
+                           float* out, float* workspace, int B, int N, int D, void* stream) {
+  return weighted_tokens_launch(tok, tok_stride_b, scale, pe, w, out, workspace, B, N, D, 1, stream);
+}
+
+// K weight vectors per image in one pass over the tokens (instruction sweep): w [K, B, N] -> out [K, B, D];
+// slice k equals what cogaim_weighted_tokens returns for w[k], bit for bit.
+int cogaim_weighted_tokens_multi(const float* tok, long long tok_stride_b, const float* w, float* out, float* workspace,
+                                 int B, int N, int D, int K, void* stream) {
+  return weighted_tokens_launch(tok, tok_stride_b, nullptr, nullptr, w, out, workspace, B, N, D, K, stream);
+}
+
 int cogaim_guided_attention(const float* a, const float* mask, float* out, int B, int N, float alpha, float temperature,
                             void* stream) {
-  if (B <= 0 || N <= 0 || temperature <= 0.f) return COGAIM_EINVAL;
-  hipLaunchKernelGGL(guided_attention_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, mask, out, N, alpha,
+  return cogaim_guided_attention_multi(a, mask, out, B, N, 1, alpha, temperature, stream);
+}
+
+// masks [K, N] against one base attention a [B, N] -> out [K, B, N]
+int cogaim_guided_attention_multi(const float* a, const float* masks, float* out, int B, int N, int K, float alpha,
+                                  float temperature, void* stream) {
+  if (B <= 0 || N <= 0 || K <= 0 || K > 65535 || temperature <= 0.f) return COGAIM_EINVAL;
+  hipLaunchKernelGGL(guided_attention_kernel, dim3(B, K), dim3(256), 0, (hipStream_t)stream, a, masks, out, N, alpha,
                      1.0f / temperature);
   return COGAIM_LAUNCH_CHECK();
 }

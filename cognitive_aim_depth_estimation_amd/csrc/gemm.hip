@@ -77,6 +77,27 @@ __device__ __forceinline__ void store_half8x2_lines(T* row, long long ldc, const
   __builtin_nontemporal_store(second, reinterpret_cast<u4*>(p_second));
 }
 
+// fp16 range guard.  Outputs stored as fp16 become inf above 65504; the epilogues that store 16-bit values keep a
+// per-lane running maximum of |y| (one v_max3_f32 per two outputs, operands are results of vector instructions,
+// never raw MFMA results) and raise *range_flag when a tile has seen a value fp16 cannot hold.  bf16 has fp32's
+// exponent range: nothing is tracked there.
+template <class T> struct TracksRange { static constexpr bool value = false; };
+template <> struct TracksRange<_Float16> { static constexpr bool value = true; };
+template <class T, int NV>
+__device__ __forceinline__ void track_peak(float& peak, const float (&y)[NV]) {
+  if constexpr (TracksRange<T>::value) {
+#pragma unroll
+    for (int i = 0; i + 1 < NV; i += 2)
+      asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(peak) : "v"(y[i]), "v"(y[i + 1]));
+  }
+}
+template <class T>
+__device__ __forceinline__ void flush_peak_to(int* range_flag, float peak) {
+  if constexpr (TracksRange<T>::value) {
+    if (range_flag && peak > 65504.0f) atomicOr(range_flag, 1);
+  }
+}
+
 // Guarded 16-byte load without a branch: the address is moved to element 0 of the array when the guard
 // fails and the value zeroed afterwards, so that consecutive loads of an epilogue issue back to back
 // (a branch per load makes the compiler wait for each load before the next one is issued).
@@ -89,20 +110,23 @@ __device__ __forceinline__ float4 ldg4(const float* base, size_t off, bool ok) {
 template <class T> struct EpiBiasHalf {           // out16 = (acc + bias) [* scale for n < scale_cols]
   static constexpr bool kWide = true, kResidual = false;
   static constexpr int kColVecs = 1;   // per-column vectors load_cols fills: 0 none, 1 bias, 2 bias and scale
-  T* out; const float* bias; int ldc; int scale_cols; float scale; int M, N;
+  T* out; const float* bias; int ldc; int scale_cols; float scale; int M, N; int* range_flag;
   __device__ __forceinline__ void load_cols(int n0, float4& b, float4&) const { b = ldg4(bias, n0, n0 < N); }
   __device__ __forceinline__ float4 load_res(int, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
-  __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 b, float4, float4) const {
+  __device__ __forceinline__ void flush_peak(float peak) const { flush_peak_to<T>(range_flag, peak); }
+  __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 b, float4, float4, float& peak) const {
     if (m >= M || n0 >= N) return;
     const float s = n0 < scale_cols ? scale : 1.0f;
-    *reinterpret_cast<Half4<T>*>(out + (size_t)m * ldc + n0) =
-        to_half4<T>((v[0] + b.x) * s, (v[1] + b.y) * s, (v[2] + b.z) * s, (v[3] + b.w) * s);
+    const float y[4] = {(v[0] + b.x) * s, (v[1] + b.y) * s, (v[2] + b.z) * s, (v[3] + b.w) * s};
+    track_peak<T, 4>(peak, y);
+    *reinterpret_cast<Half4<T>*>(out + (size_t)m * ldc + n0) = to_half4<T>(y[0], y[1], y[2], y[3]);
   }
-  __device__ __forceinline__ void finish8x2n(int, int m, int n0, const f32x4 (&v)[4], const float4 (&b)[4]) const {
+  __device__ __forceinline__ void finish8x2n(int, int m, int n0, const f32x4 (&v)[4], const float4 (&b)[4],
+                                             float& peak) const {
     if (m >= M) return;
     if (n0 + 40 > N || (ldc & 7) || (scale_cols & 7)) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) finish4n(0, m, n0 + 4 * (q & 1) + 32 * (q >> 1), v[q], b[q], b[q], b[q]);
+      for (int q = 0; q < 4; ++q) finish4n(0, m, n0 + 4 * (q & 1) + 32 * (q >> 1), v[q], b[q], b[q], b[q], peak);
       return;
     }
 #pragma unroll
@@ -114,12 +138,14 @@ template <class T> struct EpiBiasHalf {           // out16 = (acc + bias) [* sca
         y[4 * q] = (v[2 * h + q][0] + b[2 * h + q].x) * s; y[4 * q + 1] = (v[2 * h + q][1] + b[2 * h + q].y) * s;
         y[4 * q + 2] = (v[2 * h + q][2] + b[2 * h + q].z) * s; y[4 * q + 3] = (v[2 * h + q][3] + b[2 * h + q].w) * s;
       }
+      track_peak<T, 8>(peak, y);
       store_half8<T>(out + (size_t)m * ldc + n0 + 32 * h, y);
     }
   }
   // the same for a tile that lies wholly inside the matrix (every lane of the wave takes part): whole-line stores
   __device__ __forceinline__ bool lines_ok() const { return !(ldc & 7) && !(scale_cols & 7); }
-  __device__ __forceinline__ void finish8x2n_lines(int, int m, int n0, const f32x4 (&v)[4], const float4 (&b)[4]) const {
+  __device__ __forceinline__ void finish8x2n_lines(int, int m, int n0, const f32x4 (&v)[4], const float4 (&b)[4],
+                                                   float& peak) const {
     float y[2][8];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -130,10 +156,12 @@ template <class T> struct EpiBiasHalf {           // out16 = (acc + bias) [* sca
         y[h][4 * q + 2] = (v[2 * h + q][2] + b[2 * h + q].z) * s; y[h][4 * q + 3] = (v[2 * h + q][3] + b[2 * h + q].w) * s;
       }
     }
+    track_peak<T, 8>(peak, y[0]); track_peak<T, 8>(peak, y[1]);
     store_half8x2_lines<T>(out + (size_t)m * ldc + n0, ldc, y[0], y[1]);
   }
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
-    float4 b, l; load_cols(n0, b, l); finish4n(0, m, n0, v, b, b, b);
+    float4 b, l; load_cols(n0, b, l);
+    float peak = 0.f; finish4n(0, m, n0, v, b, b, b, peak); flush_peak(peak);
   }
 };
 
@@ -159,19 +187,22 @@ __device__ __forceinline__ float gelu_erf(float x) {
 template <class T> struct EpiBiasGeluHalf {
   static constexpr bool kWide = true, kResidual = false;
   static constexpr int kColVecs = 1;   // per-column vectors load_cols fills: 0 none, 1 bias, 2 bias and scale
-  T* out; const float* bias; int ldc; int M, N;
+  T* out; const float* bias; int ldc; int M, N; int* range_flag;
   __device__ __forceinline__ void load_cols(int n0, float4& b, float4&) const { b = ldg4(bias, n0, n0 < N); }
   __device__ __forceinline__ float4 load_res(int, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
-  __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 b, float4, float4) const {
+  __device__ __forceinline__ void flush_peak(float peak) const { flush_peak_to<T>(range_flag, peak); }
+  __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 b, float4, float4, float& peak) const {
     if (m >= M || n0 >= N) return;
-    *reinterpret_cast<Half4<T>*>(out + (size_t)m * ldc + n0) =
-        to_half4<T>(gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y), gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w));
+    const float y[4] = {gelu_erf(v[0] + b.x), gelu_erf(v[1] + b.y), gelu_erf(v[2] + b.z), gelu_erf(v[3] + b.w)};
+    track_peak<T, 4>(peak, y);
+    *reinterpret_cast<Half4<T>*>(out + (size_t)m * ldc + n0) = to_half4<T>(y[0], y[1], y[2], y[3]);
   }
-  __device__ __forceinline__ void finish8x2n(int, int m, int n0, const f32x4 (&v)[4], const float4 (&b)[4]) const {
+  __device__ __forceinline__ void finish8x2n(int, int m, int n0, const f32x4 (&v)[4], const float4 (&b)[4],
+                                             float& peak) const {
     if (m >= M) return;
     if (n0 + 40 > N || (ldc & 7)) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) finish4n(0, m, n0 + 4 * (q & 1) + 32 * (q >> 1), v[q], b[q], b[q], b[q]);
+      for (int q = 0; q < 4; ++q) finish4n(0, m, n0 + 4 * (q & 1) + 32 * (q >> 1), v[q], b[q], b[q], b[q], peak);
       return;
     }
 #pragma unroll
@@ -182,11 +213,13 @@ template <class T> struct EpiBiasGeluHalf {
         y[4 * q] = gelu_erf(v[2 * h + q][0] + b[2 * h + q].x); y[4 * q + 1] = gelu_erf(v[2 * h + q][1] + b[2 * h + q].y);
         y[4 * q + 2] = gelu_erf(v[2 * h + q][2] + b[2 * h + q].z); y[4 * q + 3] = gelu_erf(v[2 * h + q][3] + b[2 * h + q].w);
       }
+      track_peak<T, 8>(peak, y);
       store_half8<T>(out + (size_t)m * ldc + n0 + 32 * h, y);
     }
   }
   __device__ __forceinline__ bool lines_ok() const { return !(ldc & 7); }
-  __device__ __forceinline__ void finish8x2n_lines(int, int m, int n0, const f32x4 (&v)[4], const float4 (&b)[4]) const {
+  __device__ __forceinline__ void finish8x2n_lines(int, int m, int n0, const f32x4 (&v)[4], const float4 (&b)[4],
+                                                   float& peak) const {
     float y[2][8];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -195,10 +228,12 @@ template <class T> struct EpiBiasGeluHalf {
         y[h][4 * q] = gelu_erf(v[2 * h + q][0] + b[2 * h + q].x); y[h][4 * q + 1] = gelu_erf(v[2 * h + q][1] + b[2 * h + q].y);
         y[h][4 * q + 2] = gelu_erf(v[2 * h + q][2] + b[2 * h + q].z); y[h][4 * q + 3] = gelu_erf(v[2 * h + q][3] + b[2 * h + q].w);
       }
+    track_peak<T, 8>(peak, y[0]); track_peak<T, 8>(peak, y[1]);
     store_half8x2_lines<T>(out + (size_t)m * ldc + n0, ldc, y[0], y[1]);
   }
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
-    float4 b, l; load_cols(n0, b, l); finish4n(0, m, n0, v, b, b, b);
+    float4 b, l; load_cols(n0, b, l);
+    float peak = 0.f; finish4n(0, m, n0, v, b, b, b, peak); flush_peak(peak);
   }
 };
 
@@ -212,14 +247,15 @@ struct EpiResidualF32 {                            // x += (acc + bias) * layers
   __device__ __forceinline__ float4 load_res(int, int m, int n0) const {
     return ldg4(x, (size_t)m * ldc + n0, m < M && n0 < N);
   }
-  __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 b, float4 l, float4 r) const {
+  __device__ __forceinline__ void flush_peak(float) const {}
+  __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 b, float4 l, float4 r, float&) const {
     if (m >= M || n0 >= N) return;
     r.x += (v[0] + b.x) * l.x; r.y += (v[1] + b.y) * l.y;
     r.z += (v[2] + b.z) * l.z; r.w += (v[3] + b.w) * l.w;
     *reinterpret_cast<float4*>(x + (size_t)m * ldc + n0) = r;
   }
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
-    float4 b, l; load_cols(n0, b, l); finish4n(0, m, n0, v, b, l, load_res(0, m, n0));
+    float4 b, l; load_cols(n0, b, l); float pk = 0.f; finish4n(0, m, n0, v, b, l, load_res(0, m, n0), pk);
   }
 };
 
@@ -229,12 +265,13 @@ struct EpiStoreF32 {                               // batched plain fp32 store (
   float* out; int ldc; long long strideC; int M, N;
   __device__ __forceinline__ void load_cols(int, float4&, float4&) const {}
   __device__ __forceinline__ float4 load_res(int, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
-  __device__ __forceinline__ void finish4n(int z, int m, int n0, f32x4 v, float4, float4, float4) const {
+  __device__ __forceinline__ void flush_peak(float) const {}
+  __device__ __forceinline__ void finish4n(int z, int m, int n0, f32x4 v, float4, float4, float4, float&) const {
     if (m >= M || n0 >= N) return;
     *reinterpret_cast<float4*>(out + z * strideC + (size_t)m * ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
   }
   __device__ __forceinline__ void store4n(int z, int m, int n0, f32x4 v) const {
-    const float4 o = make_float4(0.f, 0.f, 0.f, 0.f); finish4n(z, m, n0, v, o, o, o);
+    const float4 o = make_float4(0.f, 0.f, 0.f, 0.f); float pk = 0.f; finish4n(z, m, n0, v, o, o, o, pk);
   }
 };
 
@@ -247,14 +284,15 @@ struct EpiPatchEmbed {                             // token row b*T+1+p = acc + 
     const int p = m % P;
     return ldg4(pos, (size_t)(1 + p) * D + n0, m < M && n0 < D);
   }
-  __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 bi, float4, float4 po) const {
+  __device__ __forceinline__ void flush_peak(float) const {}
+  __device__ __forceinline__ void finish4n(int, int m, int n0, f32x4 v, float4 bi, float4, float4 po, float&) const {
     if (m >= M || n0 >= D) return;
     const int b = m / P, p = m - b * P;
     *reinterpret_cast<float4*>(x + ((size_t)b * (P + 1) + 1 + p) * D + n0) =
         make_float4(v[0] + bi.x + po.x, v[1] + bi.y + po.y, v[2] + bi.z + po.z, v[3] + bi.w + po.w);
   }
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
-    float4 b, l; load_cols(n0, b, l); finish4n(0, m, n0, v, b, b, load_res(0, m, n0));
+    float4 b, l; load_cols(n0, b, l); float pk = 0.f; finish4n(0, m, n0, v, b, b, load_res(0, m, n0), pk);
   }
 };
 
@@ -335,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmShape g, Epi epi) {
 
   const int m_base = tm * BM + wm * 64, n_base = tn * BN + wn * 64;
   if constexpr (SWAP) {
+    float peak = 0.f;
     float4 cb[4], cl[4], xr[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) epi.load_cols(n_base + 16 * j + 4 * fq, cb[j], cl[j]);
@@ -347,7 +386,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmShape g, Epi epi) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        epi.finish4n(z, m_base + 16 * i + fr, n_base + 16 * j + 4 * fq, acc[i][j], cb[j], cl[j], xr[i][j]);
+        epi.finish4n(z, m_base + 16 * i + fr, n_base + 16 * j + 4 * fq, acc[i][j], cb[j], cl[j], xr[i][j], peak);
+    epi.flush_peak(peak);
   } else {
     float cb[4];
 #pragma unroll
@@ -366,12 +406,13 @@ constexpr int STAGE_BYTES = 2 * OP_BYTES;     // 64 KiB
 #ifdef COGAIM_STAMPS
 __device__ long long g_stamp_buf[256 * 12 * 4];
 #endif
-int g_gemm_slice_cap = 0;
-int g_gemm_band = -1;  // tile numbering of the persistent kernel: -1 = chosen per shape; tools/ may force a value
+int g_gemm_slice_cap = 0;   // changed only by builds with -DCOGAIM_TOOLS (tools/gemm_bench.py)
+int g_gemm_quads = 1;       // 0: K-split + fix-up launch for every partial last round (ditto)
+int g_gemm_band = -1;       // tile numbering of the persistent kernel: -1 = chosen per shape (ditto)
 
 #include "gemm_persistent.h"
 
-int g_gemm_diag = 0;   // timing-only diagnostic variants (wrong results); never set outside tools/
+int g_gemm_diag = 0;   // timing-only diagnostic variant (wrong results): reachable only in -DCOGAIM_TOOLS builds
 int g_gemm_algo = 2;   // 0: 128x128 kernel everywhere; 1: 256x256 ping-pong kernel, one tile per workgroup;
                        // 2: persistent 256x256 ping-pong kernel (large problems only for 1 and 2)
 
@@ -379,7 +420,8 @@ template <class T, class Epi, bool SWAP>
 int launch(const GemmShape& g, const Epi& epi, int batch, hipStream_t st, bool ragged_n = false,
            void* workspace = nullptr, long long workspace_bytes = 0) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (!ragged_n && (g.N & 3) != 0) ||
-      (g.lda & 7) != 0 || (g.ldw & 7) != 0)
+      (g.lda & 7) != 0 || (g.ldw & 7) != 0 || g.lda < g.K || g.ldw < g.K ||
+      ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) != 0 || !g.A || !g.W)
     return COGAIM_EINVAL;
   const int tm2 = (g.M + BM2 - 1) / BM2, tn2 = (g.N + BN2 - 1) / BN2;
   const long long tiles2 = (long long)tm2 * tn2;
@@ -399,25 +441,29 @@ int launch(const GemmShape& g, const Epi& epi, int batch, hipStream_t st, bool r
 extern "C" {
 
 // out16[M,N] = (A * W^T + bias), columns [0, scale_cols) additionally multiplied by scale.
+static bool bad_out(const void* out, int ldc, int N, int align) {
+  return !out || (ldc & 3) || ldc < N || (reinterpret_cast<uintptr_t>(out) & (align - 1));
+}
+
 int cogaim_gemm_bias_half(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                           int lda, int ldw, int ldc, int scale_cols, float scale, int dtype, void* workspace,
-                          long long workspace_bytes, void* stream) {
+                          long long workspace_bytes, int* range_flag, void* stream) {
   GemmShape g{A, W, M, N, K, lda, ldw, 0, 0};
-  if (ldc & 3) return COGAIM_EINVAL;
+  if (bad_out(out, ldc, N, 16) || (scale_cols & 3) || scale_cols < 0 || !bias) return COGAIM_EINVAL;
   return DISPATCH_T(dtype,
-      (launch<__bf16, EpiBiasHalf<__bf16>, true>(g, {(__bf16*)out, bias, ldc, scale_cols, scale, M, N}, 1, (hipStream_t)stream, false, workspace, workspace_bytes)),
-      (launch<_Float16, EpiBiasHalf<_Float16>, true>(g, {(_Float16*)out, bias, ldc, scale_cols, scale, M, N}, 1, (hipStream_t)stream, false, workspace, workspace_bytes)));
+      (launch<__bf16, EpiBiasHalf<__bf16>, true>(g, {(__bf16*)out, bias, ldc, scale_cols, scale, M, N, range_flag}, 1, (hipStream_t)stream, false, workspace, workspace_bytes)),
+      (launch<_Float16, EpiBiasHalf<_Float16>, true>(g, {(_Float16*)out, bias, ldc, scale_cols, scale, M, N, range_flag}, 1, (hipStream_t)stream, false, workspace, workspace_bytes)));
 }
 
 // out16[M,N] = gelu_erf(A * W^T + bias)
 int cogaim_gemm_bias_gelu_half(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                                int lda, int ldw, int ldc, int dtype, void* workspace, long long workspace_bytes,
-                               void* stream) {
+                               int* range_flag, void* stream) {
   GemmShape g{A, W, M, N, K, lda, ldw, 0, 0};
-  if (ldc & 3) return COGAIM_EINVAL;
+  if (bad_out(out, ldc, N, 16) || !bias) return COGAIM_EINVAL;
   return DISPATCH_T(dtype,
-      (launch<__bf16, EpiBiasGeluHalf<__bf16>, true>(g, {(__bf16*)out, bias, ldc, M, N}, 1, (hipStream_t)stream, false, workspace, workspace_bytes)),
-      (launch<_Float16, EpiBiasGeluHalf<_Float16>, true>(g, {(_Float16*)out, bias, ldc, M, N}, 1, (hipStream_t)stream, false, workspace, workspace_bytes)));
+      (launch<__bf16, EpiBiasGeluHalf<__bf16>, true>(g, {(__bf16*)out, bias, ldc, M, N, range_flag}, 1, (hipStream_t)stream, false, workspace, workspace_bytes)),
+      (launch<_Float16, EpiBiasGeluHalf<_Float16>, true>(g, {(_Float16*)out, bias, ldc, M, N, range_flag}, 1, (hipStream_t)stream, false, workspace, workspace_bytes)));
 }
 
 // x[M,N] += (A * W^T + bias) * layerscale      (fp32 residual stream, in place)
@@ -425,7 +471,7 @@ int cogaim_gemm_residual_f32(const void* A, const void* W, const float* bias, co
                              int M, int N, int K, int lda, int ldw, int ldc, int dtype, void* workspace,
                              long long workspace_bytes, void* stream) {
   GemmShape g{A, W, M, N, K, lda, ldw, 0, 0};
-  if (ldc & 3) return COGAIM_EINVAL;
+  if (bad_out(x, ldc, N, 16) || !bias || !layerscale) return COGAIM_EINVAL;
   EpiResidualF32 e{x, bias, layerscale, ldc, M, N};
   return DISPATCH_T(dtype, (launch<__bf16, EpiResidualF32, true>(g, e, 1, (hipStream_t)stream, false, workspace, workspace_bytes)),
                     (launch<_Float16, EpiResidualF32, true>(g, e, 1, (hipStream_t)stream, false, workspace, workspace_bytes)));
@@ -437,7 +483,8 @@ int cogaim_gemm_batched_f32(const void* A, const void* W, float* out, int M, int
                             void* stream) {
   GemmShape g{A, W, M, N, K, lda, ldw, strideA, strideW};
   // N need not be a multiple of 4: the last 4-wide store of a row may spill into the row padding
-  if ((ldc & 3) || ldc < ((N + 3) & ~3) || (strideC & 3) || (strideA & 7) || (strideW & 7) || batch <= 0)
+  if ((ldc & 3) || ldc < ((N + 3) & ~3) || (strideC & 3) || (strideA & 7) || (strideW & 7) || batch <= 0 || !out ||
+      (reinterpret_cast<uintptr_t>(out) & 15))
     return COGAIM_EINVAL;
   EpiStoreF32 e{out, ldc, strideC, M, N};
   return DISPATCH_T(dtype, (launch<__bf16, EpiStoreF32, true>(g, e, batch, (hipStream_t)stream, true)),
@@ -463,9 +510,12 @@ int cogaim_debug_stamps(void* dst) {
 }
 #endif
 int cogaim_set_gemm_algo(int algo) {
-  if (algo >= 1000) { g_gemm_slice_cap = algo - 1000; return COGAIM_OK; }   // tools/gemm_bench.py only
-  if (algo >= 200) { g_gemm_band = algo == 299 ? -1 : algo - 200; return COGAIM_OK; }   // tools/gemm_bench.py only
-  if (algo >= 100) { g_gemm_diag = 1; g_gemm_algo = algo - 100; return COGAIM_OK; }   // tools/gemm_bench.py only
+#ifdef COGAIM_TOOLS   // experiment knobs of tools/gemm_bench.py; the shipped library accepts 0, 1 and 2 only
+  if (algo >= 1000) { g_gemm_slice_cap = algo - 1000; return COGAIM_OK; }
+  if (algo == 300 || algo == 301) { g_gemm_quads = algo - 300; return COGAIM_OK; }
+  if (algo >= 200) { g_gemm_band = algo == 299 ? -1 : algo - 200; return COGAIM_OK; }
+  if (algo >= 100) { g_gemm_diag = 1; g_gemm_algo = algo - 100; return COGAIM_OK; }
+#endif
   if (algo < 0 || algo > 2) return COGAIM_EINVAL;
   g_gemm_algo = algo;
   g_gemm_diag = 0;

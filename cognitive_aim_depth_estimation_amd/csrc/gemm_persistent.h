@@ -48,6 +48,9 @@ struct PersistSched {
   int slices;
   int slice_block0;   // ... handled by workgroups [slice_block0, slice_block0 + n_split*slices), after their whole tiles
   float* ws;          // [split tile][slice][32 fragments][512 threads] float4 (slices >= 2 only)
+  int quads;          // 1: tiles [n_full, n_full + n_split) are cut into four QUADRANT items instead (one of the
+                      // four 64x32 quadrants of every wave's 128x64, i.e. a quarter of the tile's outputs over
+                      // the whole K): no partial sums, no fix-up launch, results bit-identical to a whole tile
 };
 
 __device__ __forceinline__ void tile_coords(const PersistSched& sc, int lt, int& tm, int& tn) {
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
   const int bid = blockIdx.x;
   const int full_per_block = bid < sc.nblk_full ? sc.n_full / sc.nblk_full : 0;
   const int sb = bid - sc.slice_block0;
-  const bool has_slice = sb >= 0 && sb < sc.n_split * sc.slices;
+  const bool has_slice = !sc.quads && sb >= 0 && sb < sc.n_split * sc.slices;
   const int n_items = full_per_block + (has_slice ? 1 : 0);
   if (n_items == 0) return;
   const T* const A0 = reinterpret_cast<const T*>(g.A);
@@ -103,13 +106,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
   const T* sAe[2]; const T* sAl[2]; const T* sWe[2]; const T* sWl[2];
   int d_item = 0, d_kt = 0, d_kt1 = 0;                  // DMA cursor
   bool d_valid = true;
-  auto dma_set_item = [&](int j) {
-    const Item it = item_at(j);
-    const int z = it.tile / sc.tiles_per_z, lt = it.tile - z * sc.tiles_per_z;
+  auto dma_set_tile = [&](int tile) {
+    const int z = tile / sc.tiles_per_z, lt = tile - z * sc.tiles_per_z;
     int tm, tn; tile_coords(sc, lt, tm, tn);
     const T* A = A0 + z * g.strideA;
     const T* W = W0 + z * g.strideW;
-    d_kt = it.kt0; d_kt1 = it.kt1;
     auto src = [&](const T* base, int ld, int row0, int limit, int piece, bool w_op) {
       const int r = piece * 8 + (lane >> 3);
       const int c = (lane & 7) ^ ((w_op && WIDE) ? swz_w(r) : swz_a(r));
@@ -123,6 +124,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
       sWe[u] = src(W, g.ldw, tn * BN2, g.N, pWe[u], true);
       sWl[u] = src(W, g.ldw, tn * BN2, g.N, pWl[u], true);
     }
+  };
+  auto dma_set_item = [&](int j) {
+    const Item it = item_at(j);
+    d_kt = it.kt0; d_kt1 = it.kt1;
+    dma_set_tile(it.tile);
   };
   auto dma_advance = [&]() {        // after the 4 phases of one K-tile have issued its pieces
     if (++d_kt >= d_kt1) {
@@ -242,6 +248,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
     int tm, tn; tile_coords(sc, lt, tm, tn);
     if (it.slice < 0) {
       const int m_base = tm * BM2 + wr * 128, n_base = tn * BN2 + wc * 64;
+      float peak = 0.f;           // fp16 range guard of the 16-bit epilogues (see track_peak)
       // all loads of the tile first, then the stores (see the note above the epilogues in gemm.hip)
       if constexpr (WIDE) {
         float4 cb[4], cl;
@@ -250,10 +257,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
         PIN_LOADED4(cb[0]); PIN_LOADED4(cb[1]); PIN_LOADED4(cb[2]); PIN_LOADED4(cb[3]);
         if ((tm + 1) * BM2 <= g.M && (tn + 1) * BN2 <= g.N && epi.lines_ok()) {   // wave-uniform
 #pragma unroll
-          for (int i = 0; i < 8; ++i) epi.finish8x2n_lines(z, m_base + 16 * i + fr, n_base + 8 * fq, acc[i], cb);
+          for (int i = 0; i < 8; ++i) epi.finish8x2n_lines(z, m_base + 16 * i + fr, n_base + 8 * fq, acc[i], cb, peak);
         } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) epi.finish8x2n(z, m_base + 16 * i + fr, n_base + 8 * fq, acc[i], cb);
+          for (int i = 0; i < 8; ++i) epi.finish8x2n(z, m_base + 16 * i + fr, n_base + 8 * fq, acc[i], cb, peak);
         }
       } else if constexpr (SWAP) {
         constexpr int RG = 1;   // fragment rows per group of residual loads (2 spills registers)
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
               epi.finish4n(z, m_base + 16 * (RG * part + i) + fr, n_base + 16 * jj + 4 * fq, acc[RG * part + i][jj],
-                           cb[jj], cl[jj], xr[i][jj]);
+                           cb[jj], cl[jj], xr[i][jj], peak);
         }
       } else {
         float cb[4];
@@ -297,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
           for (int jj = 0; jj < 4; ++jj)
             epi.finish4m(z, m_base + 16 * i + 4 * fq, n_base + 16 * jj + fr, acc[i][jj], cb[jj]);
       }
+      epi.flush_peak(peak);
     } else {
       float4* out = reinterpret_cast<float4*>(sc.ws) +
                     ((size_t)((it.tile - sc.n_full) * sc.slices + it.slice) * 32) * 512 + tid;
@@ -312,7 +320,68 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
                 (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
   }
-  if (wr == 0) BARRIER();          // match the extra barrier of the trailing group
+  if (wr == 0) BARRIER();          // match the extra barrier of the trailing group: both groups are level again
+
+  // ---- quadrant items: the partial last round ------------------------------------------------------
+  // Each leftover tile goes to four workgroups (on one XCD: they stream the same panels); a workgroup runs ONE
+  // phase per K-tile -- every wave its quadrant (MH, NH) -- over the whole K, with only the half of the A rows
+  // and the half of the W rows that quadrant reads staged (4 DMA pieces per wave and K-tile), two stages, two
+  // barriers per K-tile: DMA of K-tile kt+1 | wait for kt | barrier | read, 16 MFMAs | barrier.
+  if (sc.quads) {
+    const int qt = ((bid >> 5) << 3) + (bid & 7), q = (bid >> 3) & 3;
+    if (qt < sc.n_split) {
+      const int tile = sc.n_full + qt;
+      dma_set_tile(tile);
+      const int z = tile / sc.tiles_per_z, lt = tile - z * sc.tiles_per_z;
+      int tm, tn; tile_coords(sc, lt, tm, tn);
+      const int m_base = tm * BM2 + wr * 128, n_base = tn * BN2 + wc * 64;
+#define QUAD_DMA(MH_, NH_, stage_)                                                                    \
+  do {                                                                                               \
+    if (MH_ == 0) DMA2(sAe, pAe, 0, stage_); else DMA2(sAl, pAl, 0, stage_);                          \
+    if (NH_ == 0) DMA2(sWe, pWe, OP_BYTES, stage_); else DMA2(sWl, pWl, OP_BYTES, stage_);            \
+  } while (0)
+#define QUAD_ITEM(MH_, NH_)                                                                           \
+  do {                                                                                               \
+    f32x4 qa[4][2];                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) qa[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};          \
+    d_kt = 0;                                                                                        \
+    QUAD_DMA(MH_, NH_, 0);                                                                           \
+    for (int kt = 0; kt < nk; ++kt) {                                                                \
+      const int st = kt & 1;                                                                         \
+      const int boff = st * STAGE_BYTES;                                                             \
+      if (kt + 1 < nk) { d_kt = kt + 1; QUAD_DMA(MH_, NH_, st ^ 1); WAIT_LOAD(4); } else { WAIT_LOAD(0); } \
+      BARRIER();                                                                                     \
+      v8 af[2][4], wf[2][2];                                                                         \
+      LOAD_A(af, MH_);                                                                               \
+      LOAD_W(wf, NH_);                                                                               \
+      __builtin_amdgcn_s_setprio(1);                                                                 \
+      _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                               \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                               \
+      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                               \
+        qa[i_][j_] = SWAP ? H::mfma16(wf[s_][j_], af[s_][i_], qa[i_][j_])                            \
+                          : H::mfma16(af[s_][i_], wf[s_][j_], qa[i_][j_]);                           \
+      __builtin_amdgcn_s_setprio(0);                                                                 \
+      BARRIER();                                                                                     \
+    }                                                                                                \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                 \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                               \
+      const int i = MH_ * 4 + i_, jj = NH_ * 2 + j_;                                                 \
+      if constexpr (WIDE) epi.store4n(z, m_base + 16 * i + fr, n_base + 8 * fq + 4 * (jj & 1) + 32 * (jj >> 1), qa[i_][j_]); \
+      else if constexpr (SWAP) epi.store4n(z, m_base + 16 * i + fr, n_base + 16 * jj + 4 * fq, qa[i_][j_]); \
+      else epi.store4m(z, m_base + 16 * i + 4 * fq, n_base + 16 * jj + fr, qa[i_][j_]);               \
+    }                                                                                                \
+  } while (0)
+      switch (q) {                      // phase order of the main loop: (0,0) (0,1) (1,1) (1,0)
+        case 0: QUAD_ITEM(0, 0); break;
+        case 1: QUAD_ITEM(0, 1); break;
+        case 2: QUAD_ITEM(1, 1); break;
+        default: QUAD_ITEM(1, 0); break;
+      }
+#undef QUAD_ITEM
+#undef QUAD_DMA
+    }
+  }
 
 #undef DMA2
 #undef WAIT_LOAD
@@ -359,9 +428,15 @@ int launch_persistent(const GemmShape& g, const Epi& epi, int batch, hipStream_t
   const int lanes = tiles < CUS ? tiles : CUS;                 // concurrent workgroups
   // 8 x 4 blocks per XCD when the column tiles divide evenly into fours and there is more W than one L2 keeps
   const int band = (g_gemm_band >= 0) ? g_gemm_band : ((tn2 % 4 == 0 && tn2 >= 8) ? 8 : 1);
-  PersistSched sc{tm2, tn2, band, tiles_per_z, (tiles / lanes) * lanes, 0, 0, 1, 0, (float*)workspace};
+  PersistSched sc{tm2, tn2, band, tiles_per_z, (tiles / lanes) * lanes, 0, 0, 1, 0, (float*)workspace, 0};
   const int rem = tiles - sc.n_full;
-  if (rem > 0) {
+  if (rem > 0 && persistent && g_gemm_quads && rem * 4 <= lanes && lanes == CUS && nk <= 16) {
+    // a short last round of a short K: quadrant items on 4 x rem workgroups (every workgroup has whole tiles before
+    // it).  Same-box A/B at M = 43840: K = 768 shapes 3-4 us faster than K-split + fix-up launch (fc1 226 -> 222,
+    // QKV 150 -> 146), K = 3072 16 us slower (a quadrant item walks all 48 K-tiles at its latency-bound pace)
+    sc.n_split = rem;
+    sc.quads = 1;
+  } else if (rem > 0) {
     sc.n_split = rem;
     int slices = lanes / rem;
     if (slices > nk) slices = nk;

@@ -3,7 +3,6 @@
 // :482-519 EXIF prior, :908-941 fusion / decision / confidence heads).
 // Batch-many-rows x few-hundred-columns: GEMV class, one wave per output.
 #include "common.h"
-#include <dlfcn.h>
 
 namespace {
 
@@ -33,13 +32,15 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
     float bv = bias ? bias[o] : 0.f;
     if (bias_scale) bv *= bias_scale[b];
     float y = acc + bv;
-    if (act == 1) y = fmaxf(y, 0.f);
+    if (act == 1) y = y < 0.f ? 0.f : y;      // ReLU that keeps a NaN a NaN, as torch's does (fmaxf would drop it)
     out[(size_t)b * ldo + o] = y;
   }
 }
 
 // feat[b][0:E] = emb[idx[b]][0:E];  cont[b] = {focal_length, aperture, log(iso + 1)}
-// An index outside [0, num_emb) raises *err (when given) and reads row 0 instead of faulting.
+// An index outside [0, num_emb) raises *err (when given) and fills the image's row with NaN instead of
+// faulting: depth and confidence of that image come out NaN, so the bad result cannot be mistaken for a
+// prediction even by a caller that never looks at the flag.
 __global__ void exif_prep_kernel(const long long* __restrict__ idx, const float* __restrict__ fl,
                                  const float* __restrict__ ap, const float* __restrict__ iso,
                                  const float* __restrict__ emb, int num_emb, int E, float* __restrict__ feat, int ldf,
@@ -47,11 +48,13 @@ __global__ void exif_prep_kernel(const long long* __restrict__ idx, const float*
   const int b = blockIdx.x, t = threadIdx.x;
   if (b >= B) return;
   long long row = idx[b];
-  if (row < 0 || row >= num_emb) {
+  const bool bad = row < 0 || row >= num_emb;
+  if (bad) {
     if (t == 0 && err) *err = 1;
     row = 0;
   }
-  for (int e = t; e < E; e += blockDim.x) feat[(size_t)b * ldf + e] = emb[(size_t)row * E + e];
+  for (int e = t; e < E; e += blockDim.x)
+    feat[(size_t)b * ldf + e] = bad ? __builtin_nanf("") : emb[(size_t)row * E + e];
   if (t == 0) { cont[b * 3] = fl[b]; cont[b * 3 + 1] = ap[b]; cont[b * 3 + 2] = logf(iso[b] + 1.0f); }
 }
 
@@ -73,7 +76,8 @@ __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ fu
   if (lane == 0) {
     const float zd = ad + bd[0];
     depth[b] = zd > 20.f ? zd : log1pf(expf(zd));
-    const float zc = fmaxf(ac + bc[0], 0.f) * w2[0] + b2[0];
+    const float hc = ac + bc[0];
+    const float zc = (hc < 0.f ? 0.f : hc) * w2[0] + b2[0];      // NaN-keeping ReLU
     conf[b] = 1.0f / (1.0f + expf(-zc));
   }
 }
@@ -172,28 +176,6 @@ int cogaim_heatmap_postprocess(const float* attn, float* out, int B, int N, int 
   return COGAIM_LAUNCH_CHECK();
 }
 
-int cogaim_version() { return 1; }
-
-// All-gather of `count` floats per rank over RCCL on `stream` (the per-image (depth, confidence) rows of an
-// image-sharded batch).  The collective library is looked up at run time -- first a copy this process has
-// already loaded (a host framework's own RCCL, so that `comm` belongs to the library that is called), else
-// the system librccl -- which keeps libcogaim.so free of a link-time dependency for single-GPU users.
-int cogaim_allgather_f32(const float* send, float* recv, long long count, void* comm, void* stream) {
-  typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
-  static allgather_fn fn = nullptr;
-  static bool looked_up = false;
-  if (!looked_up) {
-    looked_up = true;
-    const char* names[] = {"librccl.so.1", "librccl.so"};
-    void* h = nullptr;
-    for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-    for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW);
-    if (h) fn = (allgather_fn)dlsym(h, "ncclAllGather");
-  }
-  if (!fn) return -38;                                    // ENOSYS: no RCCL in this process or on this host
-  if (!send || !recv || count < 0 || !comm) return COGAIM_EINVAL;
-  const int rc = fn(send, recv, (size_t)count, /* ncclFloat32 */ 7, comm, (hipStream_t)stream);
-  return rc == 0 ? COGAIM_OK : -2000 - rc;
-}
+int cogaim_version() { return 2; }
 
 }  // extern "C"

@@ -38,6 +38,11 @@ from ._lib import call, ptr, stream_ptr
 
 LOG2E = 1.4426950408889634
 _DTYPES = {"bf16": (0, torch.bfloat16), "fp16": (1, torch.float16)}
+# device-side condition words (int32 each) of a workspace: one per focal iteration, then the named ones
+_FLAG_WORDS = 64
+_MAX_ITERATIONS = 48
+_FLAG_RANGE = 60        # a 16-bit store exceeded the fp16 range (fp16 operands only)
+_FLAG_CAMERA = 63       # camera_idx outside the embedding table
 
 
 # --------------------------------------------------------------------------
@@ -207,6 +212,8 @@ class CognitiveAimModel(nn.Module):
             self.use_focal, self.use_iterative = True, True
             self.num_iterations = int(focal_cfg.get("num_iterations", 3))
             self.focus_strength = float(focal_cfg.get("focus_strength", 1.5))
+            if not 1 <= self.num_iterations <= _MAX_ITERATIONS:
+                raise ValueError(f"focal_config.num_iterations must be in 1..{_MAX_ITERATIONS}")
             if config.get("focal_hidden_dim", 256) != 256:
                 raise NotImplementedError("focal_hidden_dim != 256")
         elif "focal_stream" in modules:
@@ -252,16 +259,30 @@ class CognitiveAimModel(nn.Module):
                 node.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
         self._packed = None
         self._packed_sig = None
+        self._weights_epoch = 0
         self._ws: Dict[tuple, dict] = {}
         self._tab: Dict[tuple, torch.Tensor] = {}
         self.fusion_features = None
 
     # ------------------------------------------------------------------ packing
+    # The 16-bit GEMM copies of the weights are rebuilt when the weights change.  Every nn.Module route that
+    # replaces or rewrites parameters goes through _apply (.to / .cuda / .float ...) or load_state_dict, which
+    # bump an epoch; code that edits a parameter tensor in place calls refresh_weights() itself.
+    def _apply(self, fn, *a, **k):
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._weights_epoch += 1
+        return super().load_state_dict(*a, **k)
+
+    def refresh_weights(self):
+        """Call after modifying parameter tensors in place (``p.data.mul_(..)``): the packed 16-bit copies and
+        the captured launch graphs are rebuilt on the next forward."""
+        self._weights_epoch += 1
+
     def _signature(self):
-        sig = [self.compute_dtype]
-        for p in self.parameters():
-            sig.append((p.data_ptr(), p._version))
-        return tuple(sig)
+        return (self.compute_dtype, self._weights_epoch)
 
     def _pack(self):
         """16-bit copies of the GEMM weights, fused QK matrices; refreshed whenever a
@@ -277,10 +298,13 @@ class CognitiveAimModel(nn.Module):
         _, tdt = _DTYPES[self.compute_dtype]
         D = self.feature_dim
         pk: Dict[str, object] = {"device": dev}
+        # The patch embedding takes fp16 operands whatever compute_dtype says: its inputs are normalised pixels
+        # and convolution weights, bounded by construction, so the 8-bit significand of bf16 would only cost
+        # accuracy (it was the largest single contribution to the bf16 depth error) at the same MFMA rate.
         w = sd["backbone.embeddings.patch_embeddings.projection.weight"].reshape(D, -1)
         kp = (w.shape[1] + 63) // 64 * 64
-        wp = torch.zeros(D, kp, device=dev, dtype=tdt)
-        wp[:, :w.shape[1]] = w.to(tdt)
+        wp = torch.zeros(D, kp, device=dev, dtype=torch.float16)
+        wp[:, :w.shape[1]] = w.to(torch.float16)
         pk["pe_w"], pk["pe_kp"] = wp, kp
         pk["pe_b"] = sd["backbone.embeddings.patch_embeddings.projection.bias"].float().contiguous()
         pk["cls"] = sd["backbone.embeddings.cls_token"].float().reshape(D).contiguous()
@@ -376,8 +400,8 @@ class CognitiveAimModel(nn.Module):
             "rmax": torch.empty(B, N, **f32), "rinv": torch.empty(B, N, **f32),
             "part": torch.empty(B * nblk * N, **f32), "attn": torch.empty(B, N, **f32),
             "scale": torch.empty(2, B, N, **f32), "stats": torch.empty(B, 2, device=dev, dtype=torch.float64),
-            "flags": torch.zeros(16, device=dev, dtype=torch.int32),
-            "flags_host": torch.zeros(16, dtype=torch.int32).pin_memory(), "flags_event": torch.cuda.Event(),
+            "flags": torch.zeros(_FLAG_WORDS, device=dev, dtype=torch.int32),
+            "flags_host": torch.zeros(_FLAG_WORDS, dtype=torch.int32).pin_memory(), "flags_event": torch.cuda.Event(),
             "u": torch.empty(B, N, **f32), "usum": torch.empty(B, **f32),
             "wt": torch.empty(B, D, **f32), "w": torch.empty(B, D, **f32),
             "wtpart": torch.empty(B * ((N + call("cogaim_weighted_tokens_rows") - 1)
@@ -413,21 +437,22 @@ class CognitiveAimModel(nn.Module):
         pos = self._table("pos", gh, gw)
         x, h, qk, ctx, big = (ws[k].data_ptr() for k in ("x", "h", "qk", "ctx", "big"))
         gw, gwb = ws["gemm_ws"].data_ptr(), ws["gemm_ws"].numel()
+        rf = ws["flags"].data_ptr() + 4 * _FLAG_RANGE
         if images is not None:                 # eager: reads the caller's tensor (everything after it is static)
-            call("cogaim_im2col", images.data_ptr(), big, B, Hi, Wi, p, pk["pe_kp"], dt, st)
+            call("cogaim_im2col", images.data_ptr(), big, B, Hi, Wi, p, pk["pe_kp"], 1, st)
             return
         call("cogaim_cls_row", ptr(pk["cls"]), ptr(pos), x, B, T, D, st)
-        call("cogaim_gemm_patch_embed", big, ptr(pk["pe_w"]), ptr(pk["pe_b"]), ptr(pos), x, B, N, D, pk["pe_kp"], dt, gw, gwb, st)
+        call("cogaim_gemm_patch_embed", big, ptr(pk["pe_w"]), ptr(pk["pe_b"]), ptr(pos), x, B, N, D, pk["pe_kp"], 1, gw, gwb, st)
         qscale = 64 ** -0.5 * LOG2E
         eps = self.layer_norm_eps
         for L in pk["layers"]:
             call("cogaim_layernorm", x, ptr(L["g1"]), ptr(L["b1"]), h, M, D, eps, dt, st)
             # one projection GEMM for query | key | value (the query columns carry the softmax scale)
-            call("cogaim_gemm_bias_half", h, ptr(L["wqkv"]), ptr(L["bqkv"]), qk, M, 3 * D, D, D, D, 3 * D, D, qscale, dt, gw, gwb, st)
+            call("cogaim_gemm_bias_half", h, ptr(L["wqkv"]), ptr(L["bqkv"]), qk, M, 3 * D, D, D, D, 3 * D, D, qscale, dt, gw, gwb, rf, st)
             call("cogaim_mhsa_qkv_fwd", qk, ctx, B, T, H, 3 * D, dt, st)
             call("cogaim_gemm_residual_f32", ctx, ptr(L["wo"]), ptr(L["bo"]), ptr(L["ls1"]), x, M, D, D, D, D, D, dt, gw, gwb, st)
             call("cogaim_layernorm", x, ptr(L["g2"]), ptr(L["b2"]), h, M, D, eps, dt, st)
-            call("cogaim_gemm_bias_gelu_half", h, ptr(L["w1"]), ptr(L["bf1"]), big, M, 4 * D, D, D, D, 4 * D, dt, gw, gwb, st)
+            call("cogaim_gemm_bias_gelu_half", h, ptr(L["w1"]), ptr(L["bf1"]), big, M, 4 * D, D, D, D, 4 * D, dt, gw, gwb, rf, st)
             call("cogaim_gemm_residual_f32", big, ptr(L["w2"]), ptr(L["bf2"]), ptr(L["ls2"]), x, M, D, 4 * D, 4 * D, 4 * D, D, dt, gw, gwb, st)
         call("cogaim_layernorm", x, ptr(pk["gf"]), ptr(pk["bf"]), ws["tokens"].data_ptr(), M, D, eps, 2, st)
 
@@ -449,12 +474,12 @@ class CognitiveAimModel(nn.Module):
             call("cogaim_focal_prep", tok, tstride, s_in, ptr(pe), h, B, N, D, dt, st)
             # Y = X~ M^T + v into the first D columns' worth of the qk buffer, then S[b] = Y[b] X~[b]^T (log2 domain)
             call("cogaim_gemm_bias_half", h, ptr(f["wm"]), ptr(f["bv"]), qk, B * N, D, D, D, D, D, 0, 1.0, dt,
-                 ws["gemm_ws"].data_ptr(), ws["gemm_ws"].numel(), st)
+                 ws["gemm_ws"].data_ptr(), ws["gemm_ws"].numel(), ws["flags"].data_ptr() + 4 * _FLAG_RANGE, st)
             call("cogaim_gemm_batched_f32", qk, h, S, N, N, D, D, D, ldS, N * D, N * D, N * ldS, B, dt, st)
             call("cogaim_focal_softmax_stats_colsum", S, ldS, N * ldS, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["part"]), B, N, st)
             call("cogaim_focal_attention_vector", ptr(ws["part"]), ptr(cb), ptr(ws["attn"]), ptr(ws["stats"]),
                  s_in, s_out, self.focus_strength, B, N, st)
-            call("cogaim_focal_var_flag", ptr(ws["stats"]), B, N, ptr(ws["flags"]), i % 16, st)
+            call("cogaim_focal_var_flag", ptr(ws["stats"]), B, N, ptr(ws["flags"]), i, st)
             call("cogaim_focal_weighted_colsum", S, ldS, N * ldS, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["attn"]), ptr(ws["part"]), B, N, st)
             call("cogaim_focal_reduce_u", ptr(ws["part"]), ptr(ws["u"]), ptr(ws["usum"]), B, N, st)
             call("cogaim_weighted_tokens", tok, tstride, s_in, ptr(pe), ptr(ws["u"]), ptr(ws["wt"]), ptr(ws["wtpart"]), B, N, D, st)
@@ -474,7 +499,10 @@ class CognitiveAimModel(nn.Module):
         has variance far above the threshold), so a set flag is reported, not emulated.
 
         The flags are copied to pinned host memory asynchronously and examined at the next
-        call on this workspace or in ``synchronize()``: no host stall inside the forward."""
+        call on this workspace or in ``synchronize()``: no host stall inside the forward.  A caller
+        that runs a single forward and wants these conditions raised calls ``model.synchronize()``
+        after it.  An out-of-range camera index additionally makes that image's depth and
+        confidence NaN, so its result cannot pass for a prediction."""
         self._examine_flags(ws)
         ws["flags_host"].copy_(ws["flags"], non_blocking=True)
         ws["flags_event"].record()
@@ -487,10 +515,17 @@ class CognitiveAimModel(nn.Module):
             elif not ws["flags_event"].query():
                 return
             ws["flags_pending"] = False
-            if int(ws["flags_host"][15]):
-                ws["flags"][15] = 0
-                raise IndexError("camera_idx out of range in an earlier forward (index out of range in self)")
-            if ws["N"] > 1 and bool(ws["flags_host"][: self.num_iterations].any()):
+            host = ws["flags_host"]
+            if int(host[_FLAG_CAMERA]):
+                ws["flags"][_FLAG_CAMERA] = 0
+                raise IndexError("camera_idx out of range in an earlier forward (index out of range in self); "
+                                 "depth and confidence of that image are NaN")
+            if int(host[_FLAG_RANGE]):
+                ws["flags"][_FLAG_RANGE] = 0
+                raise OverflowError("an activation exceeded the fp16 range (65504) in an earlier forward and was "
+                                    "stored as inf: results of that call are not valid.  Build the model with "
+                                    "compute_dtype='bf16' (same speed, fp32 exponent range) for these weights")
+            if ws["N"] > 1 and bool(host[: self.num_iterations].any()):
                 raise RuntimeError("focal attention variance fell below 1e-6 in an earlier forward: the "
                                    "reference's degenerate-attention fallbacks (src/model.py:242-257) are not built")
 
@@ -527,9 +562,9 @@ class CognitiveAimModel(nn.Module):
         reads the caller's tensors."""
         idx, fl, ap, iso = exif_in
         emb = self._packed["f32"]["exif_prior.camera_embedding.weight"]
-        # an out-of-range camera index is reported through flag slot 15 (examined with the other flags)
+        # an out-of-range camera index makes the image's outputs NaN and is reported with the other flags
         call("cogaim_exif_prep", ptr(idx), ptr(fl), ptr(ap), ptr(iso), ptr(emb), emb.shape[0], 64, ptr(ws["exf"]), 128,
-             ptr(ws["cont"]), B, ws["flags"].data_ptr() + 15 * 4, stream_ptr())
+             ptr(ws["cont"]), B, ws["flags"].data_ptr() + _FLAG_CAMERA * 4, stream_ptr())
 
     def _exif(self, ws, B, col):
         self._linear(ptr(ws["cont"]), 3, "exif_prior.exif_encoder.0", ptr(ws["t64"]), 64, B, act=1)
@@ -580,7 +615,7 @@ class CognitiveAimModel(nn.Module):
         self._check_fallback_flags(ws)
         return ws["fused"].clone()
 
-    def _features(self, images, exif_data, ws, B, focal_override=None, heads=True, graph_key=None):
+    def _features(self, images, exif_data, ws, B, focal_override=None, heads=True, graph_key=None, tail=None):
         """Fills ws['cat'] with [ambient | focal | exif] (zero where a module is absent), then (``heads``)
         ws['fused'] and ws['out'].  Returns the number of feature columns filled.
 
@@ -615,6 +650,8 @@ class CognitiveAimModel(nn.Module):
                 col += 64
             if heads:           # absent modules leave zero columns, as the reference's zero padding does (:1032-1045)
                 self._heads(ws, B)
+            if tail is not None:
+                tail()
 
         self._run(ws, (graph_key, exif_in is not None, heads), body)
         return ncols
@@ -675,7 +712,15 @@ class CognitiveAimModel(nn.Module):
         reference re-creates with fresh random weights on every guided call (:1417-1422);
         when omitted a new ``nn.Linear(768, 64)`` is drawn from torch's global RNG exactly
         as the reference does, so guided depth is as irreproducible here as it is there.
+
+        ``attention_guidance`` may also be a list of K instructions (strings or tensors): the
+        backbone and the focal stream, which do not depend on the instruction (:1257), run once
+        and the K masks are applied together.  The result is what K single calls in list order
+        return, stacked: depth [K,B,1], confidence [K,B,1] (and attention [K,B,N]);
+        ``temp_projection`` is then one pair for all, or a list of K pairs.
         """
+        if isinstance(attention_guidance, (list, tuple)):
+            return self._guided_sweep(images, exif_data, list(attention_guidance), return_attention, temp_projection)
         if images.dim() == 4 and images.shape[0] == 0:
             return self._empty_outputs(images, return_attention)
         if not self.use_focal or attention_guidance is None:
@@ -720,6 +765,100 @@ class CognitiveAimModel(nn.Module):
         if return_attention:
             return depth, conf, attn
         return depth, conf
+
+    def _guided_sweep(self, images, exif_data, guidances, return_attention, temp_projection):
+        """K instructions over one backbone + focal pass (reference src/model.py:1242-1426 applied K times to
+        the same ``base_attention``).  Bit-identical to K single calls."""
+        K = len(guidances)
+        if K == 0:
+            raise ValueError("empty instruction list")
+        if not self.use_focal or any(g is None for g in guidances) or (images.dim() == 4 and images.shape[0] == 0):
+            outs = [self.forward_with_guidance(images, exif_data, g, return_attention, temp_projection=tp)
+                    for g, tp in zip(guidances, self._projection_list(temp_projection, K, draw=False))]
+            return tuple(torch.stack([o[i] for o in outs]) if outs[0][i] is not None else None
+                         for i in range(len(outs[0])))
+        images, ws, B = self._prepare(images)
+        N, D, T = ws["N"], self.feature_dim, ws["T"]
+        dev = self._packed["device"]
+        names = tuple(g.lower() if isinstance(g, str) else None for g in guidances)
+        mkey = ("masks", names, N) if all(n is not None for n in names) else None
+        masks = self._tab.get(mkey) if mkey else None
+        if masks is None:
+            rows = []
+            for g in guidances:
+                v = tables.guidance_vector(g, N)
+                if v.numel() != N:
+                    raise ValueError("attention_guidance cannot be resized to the patch grid")
+                rows.append(v.reshape(N).float())
+            masks = torch.stack(rows).to(dev).contiguous()
+            if mkey:
+                self._tab[mkey] = masks
+        sw = ws.setdefault("sweep", {}).get(K)
+        if sw is None:
+            f32 = dict(device=dev, dtype=torch.float32)
+            nchunk = (N + call("cogaim_weighted_tokens_rows") - 1) // call("cogaim_weighted_tokens_rows")
+            sw = {"guided": torch.empty(K, B, N, **f32), "wt": torch.empty(K * B, D, **f32),
+                  "wtpart": torch.empty(K * B * nchunk * D, **f32), "cat": torch.empty(K, B, 192, **f32),
+                  "fused": torch.empty(K * B, 192, **f32), "out": torch.empty(2, K * B, **f32),
+                  "pw": torch.empty(K, 64, D, **f32), "pb": torch.empty(K, 64, **f32)}
+            ws["sweep"][K] = sw
+        for k, (w, b) in enumerate(self._projection_list(temp_projection, K, draw=True)):
+            sw["pw"][k].copy_(w.reshape(64, D), non_blocking=True)       # static buffers: the captured sequence
+            sw["pb"][k].copy_(b.reshape(64), non_blocking=True)          # reads these addresses
+        col_focal = []
+
+        def tail():
+            st, f = stream_ptr(), self._packed["f32"]
+            col = col_focal[0]
+            call("cogaim_guided_attention_multi", ptr(ws["attn"]), ptr(masks), ptr(sw["guided"]), B, N, K, 0.7, 0.05, st)
+            call("cogaim_weighted_tokens_multi", ws["tokens"].data_ptr() + D * 4, T * D, ptr(sw["guided"]), ptr(sw["wt"]),
+                 ptr(sw["wtpart"]), B, N, D, K, st)
+            sw["cat"].copy_(ws["cat"].unsqueeze(0).expand(K, B, 192))      # ambient / EXIF columns of every image
+            for k in range(K):
+                self._linear(sw["wt"].data_ptr() + k * B * D * 4, D, None, sw["cat"].data_ptr() + (k * B * 192 + col) * 4,
+                             192, B, W=sw["pw"][k], bias=sw["pb"][k])
+            self._linear(ptr(sw["cat"]), 192, "fusion.0", ptr(sw["fused"]), 192, K * B, act=1)
+            out = sw["out"]
+            call("cogaim_heads", ptr(sw["fused"]), 192, ptr(f["decision_head.0.weight"]), ptr(f["decision_head.0.bias"]),
+                 ptr(f["confidence_head.0.weight"]), ptr(f["confidence_head.0.bias"]),
+                 ptr(f["confidence_head.2.weight"]), ptr(f["confidence_head.2.bias"]),
+                 out.data_ptr(), out.data_ptr() + K * B * 4, K * B, st)
+
+        ncols = self._features(images, exif_data, ws, B, focal_override=col_focal.append, heads=False,
+                               graph_key=("sweep", masks.data_ptr(), K) if mkey else None, tail=tail)
+        self._check_fallback_flags(ws)
+        attn = sw["guided"].clone()
+        self._last_attention_weights = attn[K - 1]            # what the last of K single calls leaves (:1212)
+        if ncols != 192:
+            # every single call would fall back to forward() (:1226, :1237-1240) with the guided map kept cached
+            last = self._last_attention_weights
+            out = self.forward(images, exif_data, False)
+            self._last_attention_weights = last
+            depth, conf = (o.unsqueeze(0).expand(K, B, 1).clone() for o in out)
+        else:
+            o = sw["out"].clone()
+            depth, conf = o[0].reshape(K, B, 1), o[1].reshape(K, B, 1)
+        if return_attention:
+            return depth, conf, attn
+        return depth, conf
+
+    def _projection_list(self, temp_projection, K, draw):
+        """K (weight, bias) pairs for the per-call Linear(768,64) of src/model.py:1417-1422: the caller's pair for all,
+        the caller's K pairs, or (``draw``) K fresh nn.Linear initialisations in call order."""
+        if temp_projection is None:
+            if not draw:
+                return [None] * K
+            pairs = []
+            for _ in range(K):
+                lin = nn.Linear(self.feature_dim, 64)
+                pairs.append((lin.weight.detach(), lin.bias.detach()))
+            return pairs
+        if isinstance(temp_projection, (list,)) or (isinstance(temp_projection, tuple) and len(temp_projection) == K
+                                                    and isinstance(temp_projection[0], (tuple, list))):
+            if len(temp_projection) != K:
+                raise ValueError(f"{len(temp_projection)} projections for {K} instructions")
+            return [tuple(t) for t in temp_projection]
+        return [tuple(temp_projection)] * K
 
     # training-only helpers of the reference that callers may probe for
     def compute_curiosity_loss(self, *a, **k):

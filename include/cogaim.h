@@ -16,7 +16,11 @@
  *    when the launch itself failed;
  *  - `dtype` selects the 16-bit operand type: 0 = bf16, 1 = fp16 (accumulation is fp32);
  *  - matrices are row-major; "16-bit [M,K]" operands are K-contiguous with a
- *    leading dimension in ELEMENTS that is a multiple of 8.
+ *    leading dimension in ELEMENTS that is a multiple of 8 and at least K; GEMM operand and
+ *    output base pointers are 16-byte aligned, output leading dimensions at least N (else -22);
+ *  - `range_flag` (GEMMs that store 16-bit results; may be NULL): with dtype 1 (fp16) the word it
+ *    points to is OR-ed with 1 when a result exceeds the largest finite fp16 value, 65504 (the
+ *    stored value is then inf); never written with dtype 0.  The caller zeroes it.
  */
 #ifndef COGAIM_H
 #define COGAIM_H
@@ -38,20 +42,14 @@ int cogaim_preprocess_rgb8(const void* src, int src_h, int src_w, long long src_
                            const int* xcoefs, int xk, const int* ybounds, const int* ycoefs, int yk, void* tmp,
                            const float* lut, float* dst, int out_h, int out_w, void* stream);
 
-/* Multi-GPU: the only data-path exchange of the image-sharded forward (one process per GPU, weights
- * replicated) -- every rank contributes `count` floats (its [B_local, 2] depth/confidence rows) and
- * receives world_size * count.  Wraps ncclAllGather of the RCCL copy already loaded in the process (or
- * the system one); `comm` is that library's ncclComm_t.  The reference has no multi-GPU path
- * (demo.py:406-432 is a sequential single-device loop).  Returns -38 when no RCCL can be found. */
-int cogaim_allgather_f32(const float* send, float* recv, long long count, void* comm, void* stream);
-
 /* The GEMM entry points take an optional `workspace` (device memory, `workspace_bytes` long;
  * NULL/0 allowed).  With at least cogaim_gemm_workspace_bytes() bytes they split the tiles of
  * a partial last round along K over the idle CUs (fp32 partials, summed in fixed order: results
  * stay bit-reproducible).  No counterpart in the reference. */
 long long cogaim_gemm_workspace_bytes(void);
 /* tuning knob: 0 = 128x128-tile kernel for every problem, 1 = 256x256 kernel (one tile per workgroup),
- * 2 (default) = persistent 256x256 kernel; 1 and 2 apply to large problems only */
+ * 2 (default) = persistent 256x256 kernel; 1 and 2 apply to large problems only.  Any other value: -22.
+ * Process-wide and not synchronised: set it before launching from several threads. */
 int cogaim_set_gemm_algo(int algo);
 
 /* ---- DINOv2 backbone --------------------------------------------------- */
@@ -79,7 +77,7 @@ int cogaim_layernorm(const float* x, const float* gamma, const float* beta, void
  * stream's query_proj/key_proj (src/model.py:192-193, scale 1/sqrt(D//8) of :69,197). */
 int cogaim_gemm_bias_half(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int lda,
                           int ldw, int ldc, int scale_cols, float scale, int dtype, void* workspace,
-                          long long workspace_bytes, void* stream);
+                          long long workspace_bytes, int* range_flag, void* stream);
 
 /* hf:153-178 softmax(Q K^T * dh^-0.5) V for all heads (dh = 64), flash style, on the fused projection buffer
  * (hf:203-234 computes query, key and value from the same hidden state: one cogaim_gemm_bias_half with the
@@ -95,7 +93,8 @@ int cogaim_gemm_residual_f32(const void* A, const void* W, const float* bias, co
 
 /* hf:293-295 fc1 + exact (erf) GELU: out16[M,N] = gelu(A . W^T + bias). */
 int cogaim_gemm_bias_gelu_half(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int lda,
-                               int ldw, int ldc, int dtype, void* workspace, long long workspace_bytes, void* stream);
+                               int ldw, int ldc, int dtype, void* workspace, long long workspace_bytes, int* range_flag,
+                               void* stream);
 
 /* ---- focal stream (src/model.py:128-313, 391-455) ----------------------- */
 
@@ -141,6 +140,15 @@ int cogaim_weighted_tokens(const float* tok, long long tok_stride_b, const float
 int cogaim_guided_attention(const float* a, const float* mask, float* out, int B, int N, float alpha, float temperature,
                             void* stream);
 
+/* The same for K instructions at once (the base attention of src/model.py:1257 does not depend on the
+ * instruction, only the mask of :1262-1398 does): masks [K,N], a [B,N] -> out [K,B,N]; slice k is bit-identical
+ * to cogaim_guided_attention with masks[k].  Then the guided token sums of :1412-1414 for all K in one pass:
+ * w [K,B,N] -> out [K,B,D] (no scale / position table), workspace fp32 [K*B*ceil(N/rows)*D]. */
+int cogaim_guided_attention_multi(const float* a, const float* masks, float* out, int B, int N, int K, float alpha,
+                                  float temperature, void* stream);
+int cogaim_weighted_tokens_multi(const float* tok, long long tok_stride_b, const float* w, float* out, float* workspace,
+                                 int B, int N, int D, int K, void* stream);
+
 /* ---- per-image MLPs and heads ------------------------------------------- */
 
 /* nn.Linear (+ReLU) in fp32 for the ambient MLP (src/model.py:37-44), focal projection (:82-87),
@@ -150,7 +158,8 @@ int cogaim_linear_f32(const float* x, int ldx, const float* W, const float* bias
                       int ldo, int B, int O, int K, int act, void* stream);
 
 /* src/model.py:491-514: camera embedding gather and [focal_length, aperture, log(iso+1)].
- * A camera_idx outside [0, num_embeddings) sets *err_flag = 1 (if not NULL) and gathers row 0. */
+ * A camera_idx outside [0, num_embeddings) sets *err_flag = 1 (if not NULL) and fills that image's
+ * embedding with NaN, so every value derived from it is NaN (the reference raises IndexError). */
 int cogaim_exif_prep(const long long* camera_idx, const float* focal_length, const float* aperture, const float* iso,
                      const float* embedding, int num_embeddings, int emb_dim, float* feat, int ldf, float* cont, int B,
                      int* err_flag, void* stream);

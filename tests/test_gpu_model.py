@@ -13,12 +13,14 @@ from tests.util import default_exif, load_golden, rel_err, synth_model_and_sd  #
 
 torch.set_grad_enabled(False)
 
-# north-star bar: <= 1e-3 relative on fp32 depth / confidence.  It is met with fp16 MFMA
-# operands (the shipped default: 11 significand bits, fp32 accumulation).  bf16 operands
-# (8 bits) run at the same MFMA rate but land at 1-2e-3 -- the reference's own bf16
-# autocast is 1.8e-3 off its fp32 result -- so bf16 is held to a looser, documented bound.
+# north-star bar: <= 1e-3 relative on fp32 depth / confidence, for both 16-bit operand types.
+# fp16 (11 significand bits) sits at 1-2e-4.  bf16 (8 bits) sits at 4-6e-4 on the 12-layer 518-pixel geometry
+# the bar is quoted on, where the outputs average over 1369 tokens; on the 2-layer, 16..256-token golden
+# configurations the same rounding noise averages over far fewer terms (0.7-1.0e-3 measured; the reference's own
+# bf16 autocast is 1.8e-3 off its fp32 result), so those hold bf16 to 1.5e-3 and say so here.
+# Attention maps: measured max element-wise relative error x 2 (fp16 4e-3 .. 1.3e-2, bf16 3.5e-2 .. 6.3e-2).
 DEPTH_TOL = 1e-3
-TOL = {"fp16": dict(depth=1e-3, attn=2e-2), "bf16": dict(depth=5e-3, attn=0.2)}
+TOL = {"fp16": dict(depth=1e-3, depth_small=1e-3, attn=1.5e-2), "bf16": dict(depth=1e-3, depth_small=1.5e-3, attn=0.13)}
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.jsonl")
 
 
@@ -46,14 +48,14 @@ def test_golden_forward(dtype, size):
     e = dict(depth=rel_err(d, torch.from_numpy(z[key + ":depth"])), conf=rel_err(c, torch.from_numpy(z[key + ":conf"])),
              attn=rel_err(a, torch.from_numpy(z[key + ":attn"])))
     report(test="golden_forward", dtype=dtype, size=size, **e)
-    assert e["depth"] <= TOL[dtype]["depth"] and e["conf"] <= TOL[dtype]["depth"], e
+    assert e["depth"] <= TOL[dtype]["depth_small"] and e["conf"] <= TOL[dtype]["depth_small"], e
     assert e["attn"] <= TOL[dtype]["attn"], e
     # [B,1]-shaped EXIF and the no-EXIF zero-pad branch
     d2, c2 = model(x, {k: v.unsqueeze(1) for k, v in exif.items()})
     assert torch.equal(d2, d) and torch.equal(c2, c)
     d3, c3 = model(x, None)
-    assert rel_err(d3, torch.from_numpy(z[key + ":depth_noexif"])) <= TOL[dtype]["depth"]
-    assert rel_err(c3, torch.from_numpy(z[key + ":conf_noexif"])) <= TOL[dtype]["depth"]
+    assert rel_err(d3, torch.from_numpy(z[key + ":depth_noexif"])) <= TOL[dtype]["depth_small"]
+    assert rel_err(c3, torch.from_numpy(z[key + ":conf_noexif"])) <= TOL[dtype]["depth_small"]
     assert d.shape == (2, 1) and c.shape == (2, 1) and a.shape == (2, (size // 14) ** 2)
 
 
@@ -82,7 +84,7 @@ def test_golden_guided(dtype):
     d, c = model.forward_with_guidance(x, _golden_exif(z, key, "cuda"), "center", temp_projection=proj)
     e = dict(depth=rel_err(d, torch.from_numpy(z[key + ":guided_depth"])), conf=rel_err(c, torch.from_numpy(z[key + ":guided_conf"])))
     report(test="golden_guided_depth", dtype=dtype, **e)
-    assert e["depth"] <= TOL[dtype]["depth"] and e["conf"] <= TOL[dtype]["depth"], e
+    assert e["depth"] <= TOL[dtype]["depth_small"] and e["conf"] <= TOL[dtype]["depth_small"], e
 
 
 def test_golden_variants():
@@ -102,7 +104,7 @@ def test_golden_variants():
     d, c, a = model(x, _golden_exif(z, "it2:56", "cuda"), return_attention=True)
     assert rel_err(d, torch.from_numpy(z["it2:56:depth"])) <= DEPTH_TOL
     assert rel_err(c, torch.from_numpy(z["it2:56:conf"])) <= DEPTH_TOL
-    assert rel_err(a, torch.from_numpy(z["it2:56:attn"])) <= 2e-2
+    assert rel_err(a, torch.from_numpy(z["it2:56:attn"])) <= 1.5e-2
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
@@ -116,7 +118,8 @@ def test_full_size_vs_oracle(dtype):
     d, c, a = model(x.cuda(), {k: v.cuda() for k, v in exif.items()}, return_attention=True)
     e = dict(depth=rel_err(d, d_ref), conf=rel_err(c, c_ref), attn=rel_err(a, a_ref))
     report(test="full_size", dtype=dtype, depth_ref=d_ref.flatten().tolist(), depth_gpu=d.flatten().tolist(), **e)
-    assert e["depth"] <= TOL[dtype]["depth"] and e["conf"] <= TOL[dtype]["depth"], e
+    assert e["depth"] <= TOL[dtype]["depth"] and e["conf"] <= TOL[dtype]["depth"], e     # the 1e-3 bar, both types
+    assert e["attn"] <= {"fp16": 1e-2, "bf16": 8e-2}[dtype], e
     _, _, g_ref = O.forward_with_guidance(sd, x, exif, "bottom-right")
     _, _, g = model.forward_with_guidance(x.cuda(), {k: v.cuda() for k, v in exif.items()}, "bottom-right",
                                           return_attention=True)
@@ -186,7 +189,7 @@ def test_high_resolution_eight_iterations():
     e = dict(depth=rel_err(d, d_ref), conf=rel_err(c, c_ref), attn=rel_err(a, a_ref))
     report(test="config5_1036_I8", **e)
     assert a.shape == (1, 5476)
-    assert e["depth"] <= DEPTH_TOL and e["conf"] <= DEPTH_TOL and e["attn"] <= 3e-2, e
+    assert e["depth"] <= DEPTH_TOL and e["conf"] <= DEPTH_TOL and e["attn"] <= 1e-2, e
     model.synchronize()
 
 
@@ -233,3 +236,90 @@ def test_empty_batch_and_single_image():
     d1, c1 = model(x1, default_exif(1, "cuda"))
     d_ref, c_ref, _ = O.forward(sd, x1.cpu(), default_exif(1), return_attention=True)
     assert rel_err(d1, d_ref) <= DEPTH_TOL and rel_err(c1, c_ref) <= DEPTH_TOL
+
+
+def test_instruction_sweep_equals_single_calls():
+    """BASELINE config 3: the nine instructions over ONE backbone + focal pass give, bit for bit, what nine single
+    guided calls give, and match the reference's guided heat maps (tests/golden/g7_full_model.npz)."""
+    z = load_golden("g7_full_model")
+    model, _ = synth_model_and_sd(int(z["layers"]), int(z["native_grid"]), seed=int(z["seed"]), dtype="fp16")
+    names = list(O.INSTRUCTIONS)
+    for size in (56, 224):
+        key = f"full:{size}"
+        x = torch.from_numpy(z[key + ":x"]).cuda()
+        exif = _golden_exif(z, key, "cuda")
+        projs = [(torch.randn(64, 768), torch.randn(64)) for _ in names]
+        for rep in range(3):                                   # eager, capture, replay
+            D, C, A = model.forward_with_guidance(x, exif, names, return_attention=True, temp_projection=projs)
+            assert D.shape == (9, 2, 1) and C.shape == (9, 2, 1) and A.shape == (9, 2, (size // 14) ** 2)
+            assert torch.equal(model.get_attention_weights(), A[8])
+        for k, name in enumerate(names):
+            d, c, a = model.forward_with_guidance(x, exif, name, return_attention=True, temp_projection=projs[k])
+            assert torch.equal(d, D[k]) and torch.equal(c, C[k]) and torch.equal(a, A[k]), name
+            ref = torch.from_numpy(z[f"{key}:guided:{name}"])
+            assert float((A[k].cpu() - ref).abs().max() / ref.max()) <= 1e-2
+    # one projection for all, tensor guidance mixed with names, and the no-EXIF fall-back of the reference
+    g = torch.rand(196)
+    D2, C2 = model.forward_with_guidance(x, exif, ["center", g], temp_projection=projs[0])
+    d, c = model.forward_with_guidance(x, exif, g, temp_projection=projs[0])
+    assert torch.equal(D2[1], d) and torch.equal(C2[1], c)
+    D3, C3, A3 = model.forward_with_guidance(x, None, ["left", "right"], return_attention=True)
+    d0, c0 = model(x, None)
+    assert torch.equal(D3[0], d0) and torch.equal(D3[1], d0) and torch.equal(C3[1], c0)
+    assert not torch.equal(A3[0], A3[1])
+    model.synchronize()
+
+
+def test_bad_camera_index_gives_nan_and_raises():
+    """The reference raises IndexError inside the embedding lookup.  Here the image's outputs are NaN at once
+    (in-band, no host stall) and the IndexError is raised by synchronize() or the next call."""
+    import pytest as _pt
+    model, _ = synth_model_and_sd(2, 4, seed=7, dtype="fp16")
+    x = torch.randn(3, 3, 56, 56, device="cuda")
+    exif = default_exif(3, "cuda")
+    good_d, good_c = model(x, exif)
+    exif["camera_idx"][1] = 71
+    d, c = model(x, exif)
+    assert torch.isnan(d[1]).all() and torch.isnan(c[1]).all()
+    assert torch.equal(d[[0, 2]], good_d[[0, 2]]) and torch.equal(c[[0, 2]], good_c[[0, 2]])
+    with _pt.raises(IndexError):
+        model.synchronize()
+    model.synchronize()                                         # reported once
+    many, _ = synth_model_and_sd(1, 4, iters=20, seed=7, dtype="fp16")   # 20 iterations: flag words do not collide
+    many(x, default_exif(3, "cuda"))
+    many.synchronize()
+    with _pt.raises(ValueError):
+        synth_model_and_sd(1, 4, iters=49, seed=7)
+
+
+def test_fp16_range_guard_and_outlier_tokens():
+    """Weights that drive activations toward and past the fp16 range.  (1) fc1 and query/key weights scaled so
+    that hidden values and projections reach ~1e4 (outlier channels): fp16 and bf16 both stay finite and on the
+    oracle.  (2) scaled further, past 65504: the fp16 model reports it (OverflowError naming bf16 as the remedy)
+    instead of returning numbers computed from inf; the bf16 model still matches the oracle."""
+    import pytest as _pt
+    layers, grid = 2, 4
+    torch.manual_seed(3)
+    x = torch.randn(2, 3, 56, 56)
+    exif = default_exif(2)
+    for scale, overflow in ((3000.0, False), (1.0e5, True)):
+        for dtype in ("fp16", "bf16"):
+            model, sd = synth_model_and_sd(layers, grid, seed=13, dtype=dtype)
+            sd = dict(sd)
+            k = "backbone.encoder.layer.1.mlp.fc1.weight"
+            w = sd[k].clone(); w[:8] *= scale; sd[k] = w                   # 8 outlier hidden channels
+            k2 = "backbone.encoder.layer.1.mlp.fc2.weight"
+            w2 = sd[k2].clone(); w2[:, :8] /= scale; sd[k2] = w2            # ... absorbed by fc2, as trained nets do
+            model.load_state_dict(sd)
+            d_ref, c_ref = O.forward(sd, x, exif)
+            d, c = model(x.cuda(), {k_: v.cuda() for k_, v in exif.items()})
+            if overflow and dtype == "fp16":
+                with _pt.raises(OverflowError, match="bf16"):
+                    model.synchronize()
+                continue
+            model.synchronize()
+            e = dict(depth=rel_err(d, d_ref), conf=rel_err(c, c_ref))
+            report(test="range_stress", dtype=dtype, scale=scale, **e)
+            assert torch.isfinite(d).all() and torch.isfinite(c).all()
+            tol = 1e-3 if dtype == "fp16" else 4e-3        # bf16 on this 2-layer, 16-token model: see TOL above
+            assert e["depth"] <= tol and e["conf"] <= tol, (dtype, scale, e)

@@ -134,3 +134,32 @@ def test_image_sharded_gather_world_size_2(n):
         assert p.exitcode == 0
     expect = [[float(i), 100.0 + i] for i in range(n)]
     assert got[0] == expect and got[1] == expect
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` outside a launcher starts N rank processes itself (before any GPU call) and
+    rank 0 reports n_gpus = N; asking for more GPUs than are visible, or for a world size other than the one a
+    launcher started, exits non-zero instead of silently measuring fewer.  The step is stubbed (no GPU here):
+    gloo all-gather of the per-image rows + barrier + max-over-ranks timing are the real ones."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, COGAIM_BENCH_STUB="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                     # ONE line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    env.pop("COGAIM_BENCH_STUB")
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode != 0 and "refusing" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "started 2 ranks" in r.stderr

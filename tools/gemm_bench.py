@@ -52,13 +52,13 @@ def run(name):
     A, W, bias, ls, out16, x = bufs[name]
     st = stream_ptr()
     if kind == "bias3":
-        call("cogaim_gemm_bias_half", ptr(A), ptr(W), ptr(bias), ptr(out16), M, N, K, K, K, N, N // 3, 0.18, dt, *wsp, st)
+        call("cogaim_gemm_bias_half", ptr(A), ptr(W), ptr(bias), ptr(out16), M, N, K, K, K, N, N // 12 * 4, 0.18, dt, *wsp, None, st)
     elif kind == "bias":
-        call("cogaim_gemm_bias_half", ptr(A), ptr(W), ptr(bias), ptr(out16), M, N, K, K, K, N, N // 2, 0.18, dt, *wsp, st)
+        call("cogaim_gemm_bias_half", ptr(A), ptr(W), ptr(bias), ptr(out16), M, N, K, K, K, N, N // 8 * 4, 0.18, dt, *wsp, None, st)
     elif kind == "gelu":
-        call("cogaim_gemm_bias_gelu_half", ptr(A), ptr(W), ptr(bias), ptr(out16), M, N, K, K, K, N, dt, *wsp, st)
+        call("cogaim_gemm_bias_gelu_half", ptr(A), ptr(W), ptr(bias), ptr(out16), M, N, K, K, K, N, dt, *wsp, None, st)
     elif kind == "res":
-        call("cogaim_gemm_residual_f32", ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(x), M, N, K, K, K, N, dt, *wsp, st)
+        call("cogaim_gemm_residual_f32", ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(x), M, N, K, K, K, N, dt, *wsp, None, st)
 
 
 def check(name):

@@ -30,11 +30,11 @@ if len(sys.argv) > 1:
 
 def run():
     if kind == "gelu":
-        call("cogaim_gemm_bias_gelu_half", ptr(A), ptr(W), ptr(bias), ptr(out), M, N, K, K, K, N, 1, ws.data_ptr(), ws.numel(), stream_ptr())
+        call("cogaim_gemm_bias_gelu_half", ptr(A), ptr(W), ptr(bias), ptr(out), M, N, K, K, K, N, 1, ws.data_ptr(), ws.numel(), None, stream_ptr())
     elif kind == "bias":
-        call("cogaim_gemm_bias_half", ptr(A), ptr(W), ptr(bias), ptr(out), M, N, K, K, K, N, 0, 1.0, 1, ws.data_ptr(), ws.numel(), stream_ptr())
+        call("cogaim_gemm_bias_half", ptr(A), ptr(W), ptr(bias), ptr(out), M, N, K, K, K, N, 0, 1.0, 1, ws.data_ptr(), ws.numel(), None, stream_ptr())
     else:
-        call("cogaim_gemm_residual_f32", ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(x), M, N, K, K, K, N, 1, ws.data_ptr(), ws.numel(), stream_ptr())
+        call("cogaim_gemm_residual_f32", ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(x), M, N, K, K, K, N, 1, ws.data_ptr(), ws.numel(), None, stream_ptr())
 
 
 for _ in range(3):
