@@ -39,6 +39,7 @@ SIGNATURES = {
     "cogaim_focal_reduce_u": [P, P, P, I, I, P],
     "cogaim_weighted_tokens_rows": [],
     "cogaim_weighted_tokens": [P, LL, P, P, P, P, P, I, I, I, P],
+    "cogaim_weighted_tokens_static": [P, LL, P, P, P, P, I, I, I, P],
     "cogaim_guided_attention": [P, P, P, I, I, F, F, P],
     "cogaim_guided_attention_multi": [P, P, P, I, I, I, F, F, P],
     "cogaim_weighted_tokens_multi": [P, LL, P, P, P, I, I, I, I, P],

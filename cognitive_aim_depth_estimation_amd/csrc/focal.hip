@@ -12,6 +12,13 @@
 // The last two lines use sum_n a_n (P V)_n = (a^T P) V, so the N x N x D product
 // P V and the V projection of every token are never formed.
 #include "common.h"
+#include <mutex>
+
+// Partial sums of cogaim_weighted_tokens_static: device memory that belongs to the code object, one copy per GPU,
+// held until the process ends.  Host code never passes this NAME to a kernel (on the host it is a stand-in,
+// not a device address): the per-device address is looked up once with hipGetSymbolAddress below.
+#define COGAIM_WT_STATIC_FLOATS (2 * 1024 * 1024)        /* 8 MiB */
+static __device__ __align__(256) float scratch[COGAIM_WT_STATIC_FLOATS];
 
 namespace {
 
@@ -442,6 +449,37 @@ int cogaim_weighted_tokens(const float* tok, long long tok_stride_b, const float
 int cogaim_weighted_tokens_multi(const float* tok, long long tok_stride_b, const float* w, float* out, float* workspace,
                                  int B, int N, int D, int K, void* stream) {
   return weighted_tokens_launch(tok, tok_stride_b, nullptr, nullptr, w, out, workspace, B, N, D, K, stream);
+}
+
+// cogaim_weighted_tokens without a workspace argument and without any allocation: the partial sums live in the
+// library's own static device array (8 MiB per GPU).  The array's address on the current device is resolved on
+// the first call there (hipGetSymbolAddress; make that call outside a stream capture) and kept.  Every call on
+// one GPU shares the array: calls that overlap on a GPU (different streams or host threads) race.  Nothing in
+// it has to start at zero -- the partial kernel writes every element the reduction reads.
+int cogaim_weighted_tokens_static(const float* tok, long long tok_stride_b, const float* scale, const float* pe,
+                                  const float* w, float* out, int B, int N, int D, void* stream) {
+  constexpr int MAX_DEV = 64;
+  static std::mutex mu;
+  static float* dev_ptr[MAX_DEV] = {};
+  if (B <= 0 || N <= 0 || D <= 0) return COGAIM_EINVAL;
+  const long long need = (long long)B * ((N + WT_ROWS - 1) / WT_ROWS) * D;
+  if (need > (long long)COGAIM_WT_STATIC_FLOATS) return COGAIM_EINVAL;     // beyond the fixed 8 MiB of partial sums
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_rc(e);
+  if (dev < 0 || dev >= MAX_DEV) return COGAIM_EINVAL;
+  float* ws;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!dev_ptr[dev]) {
+      void* p = nullptr;
+      e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+      if (e != hipSuccess || !p) return e != hipSuccess ? hip_rc(e) : COGAIM_EINVAL;
+      dev_ptr[dev] = static_cast<float*>(p);
+    }
+    ws = dev_ptr[dev];
+  }
+  return weighted_tokens_launch(tok, tok_stride_b, scale, pe, w, out, ws, B, N, D, 1, stream);
 }
 
 int cogaim_guided_attention(const float* a, const float* mask, float* out, int B, int N, float alpha, float temperature,

@@ -136,6 +136,17 @@ int cogaim_weighted_tokens_rows(void);
 int cogaim_weighted_tokens(const float* tok, long long tok_stride_b, const float* scale, const float* pe, const float* w,
                            float* out, float* workspace, int B, int N, int D, void* stream);
 
+/* No counterpart in the reference: cogaim_weighted_tokens for callers that cannot allocate device memory or
+ * pass a workspace (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * Allocates nothing: the partial sums live in a static device array of the library, 8 MiB per GPU, held
+ * until the process ends; B * ceil(N / cogaim_weighted_tokens_rows()) * D must not exceed
+ * COGAIM_WT_STATIC_MAX_FLOATS (else -22, nothing launched).  The first call on a device looks the array up
+ * (make it outside a stream capture).  All calls on one GPU share the array: calls that overlap in time on
+ * one GPU race.  Results equal cogaim_weighted_tokens bit for bit. */
+#define COGAIM_WT_STATIC_MAX_FLOATS (2 * 1024 * 1024)
+int cogaim_weighted_tokens_static(const float* tok, long long tok_stride_b, const float* scale, const float* pe,
+                                  const float* w, float* out, int B, int N, int D, void* stream);
+
 /* src/model.py:1401-1409: out = softmax((alpha*mask + (1-alpha)*a) / temperature). */
 int cogaim_guided_attention(const float* a, const float* mask, float* out, int B, int N, float alpha, float temperature,
                             void* stream);
