@@ -156,7 +156,8 @@ def main():
     ap.add_argument("--iters", type=int, default=3, help="focal refinement iterations")
     ap.add_argument("--dtype", default=os.environ.get("COGAIM_DTYPE", "bf16"), choices=["fp16", "bf16"],
                     help="headline operand type (BASELINE config 2 is bf16); the other one is timed beside it")
-    ap.add_argument("--streams", type=int, default=1, help="split each batch over this many HIP streams")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="sub-batches the model runs on streams of its own (0 = the model's default, 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--no-second-dtype", action="store_true")
@@ -195,31 +196,20 @@ def main():
             "aperture": torch.full((B,), 2.8, device=dev), "iso": torch.full((B,), 100.0, device=dev)}
     gathered = torch.empty(world * B, 2, device=dev) if world > 1 else None
 
-    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
-    chunks = torch.arange(B).chunk(args.streams) if streams else None
+    def config_for(dtype, **extra):
+        cfg = {"cognitive_modules": MODULES, "compute_dtype": dtype,
+               "focal_config": {"num_iterations": args.iters, "focus_strength": 1.5}, "init_seed": 0}
+        if args.streams > 0:
+            cfg["streams"] = args.streams
+        cfg.update(extra)
+        return cfg
 
     def timed_run(dtype):
         """W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides (max over ranks)."""
-        cfg = {"cognitive_modules": MODULES, "compute_dtype": dtype,
-               "focal_config": {"num_iterations": args.iters, "focus_strength": 1.5}, "init_seed": 0}
-        model = create_model(cfg, {"num_cameras": 71}, device=dev)
-
-        def forward_batch():
-            if not streams:
-                return model(images, exif)
-            cur = torch.cuda.current_stream()
-            outs = []
-            for s_, idx in zip(streams, chunks):
-                s_.wait_stream(cur)
-                with torch.cuda.stream(s_):
-                    lo, hi = int(idx[0]), int(idx[-1]) + 1
-                    outs.append(model(images[lo:hi], {k: v[lo:hi] for k, v in exif.items()}))
-            for s_ in streams:
-                cur.wait_stream(s_)
-            return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+        model = create_model(config_for(dtype), {"num_cameras": 71}, device=dev)
 
         def step():
-            d, c = forward_batch()
+            d, c = model(images, exif)
             if world > 1:   # per-image scalars of every shard to every rank (RCCL over xGMI)
                 dist.all_gather_into_tensor(gathered, torch.cat([d, c], dim=1))
             return d, c
@@ -263,6 +253,7 @@ def main():
                    "global_batch": world * B, "sharding": f"image-sharded dp{world}" if world > 1 else "single GPU"},
         "algorithmic_gflop_per_image": round(fpi / 1e9, 1),
         "mfma_frac_end_to_end": frac(value),
+        "streams_per_gpu": min(model.num_streams, max(1, B // 8)),
         "by_dtype": {args.dtype: {"value": round(value, 2), "ms_per_step": round(ms_per_step, 3),
                                   "mfma_frac_end_to_end": frac(value)}},
     }
@@ -279,21 +270,21 @@ def main():
         out["by_dtype"][other] = {"value": round(v2, 2), "ms_per_step": round(1000.0 * el2 / args.steps, 3),
                                   "mfma_frac_end_to_end": frac(v2)}
         results[other] = (d2, c2)
-        if other != args.dtype:      # the per-kernel profile below belongs to the headline type
-            del model
-            torch.cuda.empty_cache()
-            model = None
 
     if rank == 0 and not args.no_kernel_profile:
-        if model is None:
-            cfg = {"cognitive_modules": MODULES, "compute_dtype": args.dtype,
-                   "focal_config": {"num_iterations": args.iters, "focus_strength": 1.5}, "init_seed": 0}
-            model = create_model(cfg, {"num_cameras": 71}, device=dev)
-            model(images, exif)
-        # per-kernel durations: HIP events on the launch stream around every C-ABI launch of 3 more steps
+        # Per-kernel durations: HIP events on the launch stream around every C-ABI launch, on ONE stream so that no
+        # two kernels overlap, at the launch shapes of the timed run (the model splits a batch into `n_sub`
+        # sub-batches on streams of its own: the sub-batch is profiled, 3 repeats, times scaled by n_sub).
+        del model
+        torch.cuda.empty_cache()
+        n_sub = out["streams_per_gpu"]
+        Bs = B // n_sub
+        model = create_model(config_for(args.dtype, streams=1), {"num_cameras": 71}, device=dev)
+        sub_img, sub_exif = images[:Bs], {k: v[:Bs] for k, v in exif.items()}
+        model(sub_img, sub_exif)
         _lib.PROFILE = []
         for _ in range(3):
-            model(images, exif)
+            model(sub_img, sub_exif)
         torch.cuda.synchronize()
         prof, _lib.PROFILE = _lib.PROFILE, None
         groups = {}
@@ -303,9 +294,10 @@ def main():
             gsum = groups.setdefault(key, [0.0, 0, fl])
             gsum[0] += e0.elapsed_time(e1)
             gsum[1] += 1
-        total_ms = sum(v[0] for v in groups.values()) / 3
+        total_ms = sum(v[0] for v in groups.values()) / 3 * n_sub
         top = sorted(groups.items(), key=lambda kv: -kv[1][0])
-        out["kernel_breakdown_ms_per_step"] = {f"{k[0]}{list(k[1]) if k[1] else ''}": round(v[0] / 3, 3) for k, v in top[:12]}
+        out["kernel_breakdown_ms_per_step"] = {f"{k[0]}{list(k[1]) if k[1] else ''}": round(v[0] / 3 * n_sub, 3)
+                                               for k, v in top[:12]}
         out["kernel_sum_ms_per_step"] = round(total_ms, 3)
         (dname, dshape), (dms, dcnt, dfl) = next((kv for kv in top if kv[1][2]), top[0])
         avg_ms = dms / dcnt
@@ -319,11 +311,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cogaim_oracle as O
-        if model is None:
-            cfg = {"cognitive_modules": MODULES, "compute_dtype": args.dtype,
-                   "focal_config": {"num_iterations": args.iters, "focus_strength": 1.5}, "init_seed": 0}
-            model = create_model(cfg, {"num_cameras": 71}, device=dev)
-        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}      # same seeded weights in every model here
         nb, nf = min(16, B), min(4, B)        # ~10-20 s of host work in total
         xc = images[:nb].cpu()
         ec = {k: v[:nb].cpu() for k, v in exif.items()}

@@ -323,3 +323,21 @@ def test_fp16_range_guard_and_outlier_tokens():
             assert torch.isfinite(d).all() and torch.isfinite(c).all()
             tol = 1e-3 if dtype == "fp16" else 4e-3        # bf16 on this 2-layer, 16-token model: see TOL above
             assert e["depth"] <= tol and e["conf"] <= tol, (dtype, scale, e)
+
+
+def test_stream_split_equals_single_stream():
+    """Batches of 16 or more run as two sub-batches on streams of the model's own; per-image results do not depend
+    on batch mates, so outputs are bit-identical to the single-stream run (eager, capture and replay calls)."""
+    two, _ = synth_model_and_sd(2, 4, seed=7, dtype="bf16")
+    one, _ = synth_model_and_sd(2, 4, seed=7, dtype="bf16")
+    one.num_streams = 1
+    assert two.num_streams == 2
+    for call_no in range(4):
+        x = torch.randn(19, 3, 98, 70, device="cuda")
+        exif = default_exif(19, "cuda")
+        a = two(x, exif, return_attention=True)
+        b = one(x, exif, return_attention=True)
+        assert all(torch.equal(u, v) for u, v in zip(a, b)), call_no
+        assert torch.equal(two.fusion_features, one.fusion_features)
+    assert len(two._ws) == 2 and len(one._ws) == 1            # one workspace (and graph) per sub-batch stream
+    two.synchronize()
