@@ -47,6 +47,8 @@ SIGNATURES = {
     "cogaim_exif_prep": [P, P, P, P, P, I, I, P, I, P, I, P, P],
     "cogaim_heads": [P, I, P, P, P, P, P, P, P, P, I, P],
     "cogaim_heatmap_postprocess": [P, P, I, I, I, P],
+    "cogaim_curiosity_sample": [P, P, P, P, P, LL, P, P, I, I, I, P],
+    "cogaim_curiosity_finish": [P, P, LL, P, P, P, P, P, P, P, P, P, I, I, I, P],
 }
 
 _NO_STATUS = {"cogaim_version", "cogaim_gemm_workspace_bytes", "cogaim_focal_colsum_rows", "cogaim_weighted_tokens_rows"}

@@ -135,9 +135,91 @@ __global__ __launch_bounds__(256) void heatmap_kernel(const float* __restrict__ 
   for (int i = tid; i < GG; i += 256) ob[i] = i < N ? (val[i] - mn) * inv : 0.f;
 }
 
+// Curiosity module, element-wise parts (reference src/model.py:608-610, 743-745):
+//   z = mu + eps * exp(0.5 * logvar)   [B, L];   noisy = cls + noise   [B, D]   (cls rows ld_cls apart)
+__global__ __launch_bounds__(256) void curiosity_sample_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                                               const float* __restrict__ eps, float* __restrict__ z,
+                                                               const float* __restrict__ cls, long long ld_cls,
+                                                               const float* __restrict__ noise, float* __restrict__ noisy,
+                                                               int L, int D) {
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < L; i += 256)
+    z[(size_t)b * L + i] = mu[(size_t)b * L + i] + eps[(size_t)b * L + i] * expf(0.5f * logvar[(size_t)b * L + i]);
+  for (int i = threadIdx.x; i < D; i += 256) noisy[(size_t)b * D + i] = cls[b * ld_cls + i] + noise[(size_t)b * D + i];
+}
+
+// Curiosity reward per image (src/model.py:616-686 with loss_type "robust", uncertainty_weight 0.1, no EXIF:
+// geometric term 0.5, :698-700) and, by one thread after all images, the ring-buffer update of :760-773 in
+// image order.  One workgroup; images are walked by the waves.
+__global__ __launch_bounds__(256) void curiosity_finish_kernel(const float* __restrict__ rec, const float* __restrict__ cls,
+                                                               long long ld_cls, const float* __restrict__ mu,
+                                                               const float* __restrict__ logvar,
+                                                               const float* __restrict__ unc_pre,
+                                                               const float* __restrict__ lb_pre,
+                                                               const float* __restrict__ ln_pre,
+                                                               const float* __restrict__ weights3, float* __restrict__ reward,
+                                                               float* __restrict__ history, long long* __restrict__ pointer,
+                                                               int B, int L, int hist_len) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float w0 = weights3[0], w1 = weights3[1], w2 = weights3[2];
+  const float wm = fmaxf(w0, fmaxf(w1, w2));
+  const float e0 = expf(w0 - wm), e1 = expf(w1 - wm), e2 = expf(w2 - wm), es = e0 + e1 + e2;
+  for (int b = wave; b < B; b += 4) {
+    float sq = 0.f, kl = 0.f;
+    for (int i = lane; i < L; i += 64) {
+      const float d = rec[(size_t)b * L + i] - cls[b * ld_cls + i];
+      const float m = mu[(size_t)b * L + i], lv = logvar[(size_t)b * L + i];
+      sq += d * d;
+      kl += 1.0f + lv - m * m - expf(lv);
+    }
+    sq = wave_sum(sq); kl = wave_sum(kl);
+    if (lane == 0) {
+      float re = sqrtf(sq + 1e-8f);
+      re = fmaxf(re / (1.0f + re), 0.f);
+      const float kld = fmaxf(-0.5f * kl, 0.f);
+      const float up = unc_pre[b];
+      const float unc = fminf(fmaxf(up > 20.f ? up : log1pf(expf(up)), 0.f), 10.f);
+      const float basic = re + 0.1f * kld + 0.1f * unc;
+      const float lb = 1.0f / (1.0f + expf(-lb_pre[b])), ln = 1.0f / (1.0f + expf(-ln_pre[b]));
+      const float local = fminf(fmaxf(lb + fabsf(lb - ln) * 0.2f, 0.f), 1.f);
+      reward[b] = (e0 / es) * 0.5f + (e1 / es) * local + (e2 / es) * basic;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && history && pointer) {
+    long long p = *pointer;
+    for (int b = 0; b < B; ++b) {
+      const long long idx = ((p % hist_len) + hist_len) % hist_len;
+      history[idx] = reward[b];
+      p = (p + 1) % hist_len;
+    }
+    *pointer = p;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+// src/model.py:608-610 and :743-745 (see curiosity_sample_kernel)
+int cogaim_curiosity_sample(const float* mu, const float* logvar, const float* eps, float* z, const float* cls,
+                            long long ld_cls, const float* noise, float* noisy, int B, int L, int D, void* stream) {
+  if (B <= 0 || L <= 0 || D <= 0) return COGAIM_EINVAL;
+  hipLaunchKernelGGL(curiosity_sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mu, logvar, eps, z, cls, ld_cls,
+                     noise, noisy, L, D);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+// src/model.py:616-686 + :760-773 (see curiosity_finish_kernel); history / pointer may be NULL (no ring update)
+int cogaim_curiosity_finish(const float* rec, const float* cls, long long ld_cls, const float* mu, const float* logvar,
+                            const float* unc_pre, const float* lb_pre, const float* ln_pre, const float* weights3,
+                            float* reward, float* history, long long* pointer, int B, int L, int hist_len, void* stream) {
+  if (B <= 0 || L <= 0 || hist_len <= 0) return COGAIM_EINVAL;
+  hipLaunchKernelGGL(curiosity_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rec, cls, ld_cls, mu, logvar,
+                     unc_pre, lb_pre, ln_pre, weights3, reward, history, pointer, B, L, hist_len);
+  return COGAIM_LAUNCH_CHECK();
+}
+
 
 // act: 0 identity, 1 ReLU.  bias / bias_scale may be NULL.
 int cogaim_linear_f32(const float* x, int ldx, const float* W, const float* bias, const float* bias_scale, float* out,

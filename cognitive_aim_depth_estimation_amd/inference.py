@@ -248,6 +248,8 @@ class CognitiveAimInference:
             raise RuntimeError("this build runs the forward pass only on an MI355X (ROCm) device; "
                                "there is no CPU path (use the reference's own demo.py for CPU runs)")
         print(f"Using device: {self.device}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.config = load_config(config_path)
         camera_info = camera_info_from_config(self.config)
         self.model = create_model(self.config, camera_info).to(self.device)
@@ -262,17 +264,44 @@ class CognitiveAimInference:
         self.preprocess = DevicePreprocessor(self.image_size, self.device)
 
     def _load_checkpoint(self, checkpoint_path: str):
-        """Tolerant loader of reference demo.py:89-150: accepts {'model_state_dict'|'main_model'|raw},
-        keeps entries whose name and shape match, and on ANY failure keeps the initial weights.
-        Unlike the reference it only unpickles tensors (weights_only=True)."""
+        """Tolerant loader of reference demo.py:89-150: the state dict is ``ckpt['model_state_dict']``, else
+        ``ckpt['main_model']``, else the file's top-level dict; entries whose name and shape match are loaded
+        (strict=False); parameters the file does not supply are re-initialised as the reference does (:136-146:
+        matrices xavier-uniform, vectors named *weight* normal(0, 0.01), *bias* zero); ANY failure keeps the
+        initial weights.  Unlike the reference it only unpickles tensors (weights_only=True)."""
         print(f"Loading checkpoint: {checkpoint_path}")
         try:
             ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
-            state = ckpt.get("model_state_dict") or ckpt.get("main_model") or ckpt
+            if "model_state_dict" in ckpt:
+                state = ckpt["model_state_dict"]
+            elif "main_model" in ckpt:
+                state = ckpt["main_model"]
+            else:
+                state = ckpt
             own = self.model.state_dict()
-            keep = {k: v for k, v in state.items() if k in own and own[k].shape == v.shape}
+            keep, skipped = {}, 0
+            for k, v in state.items():
+                if k in own and own[k].shape == v.shape:
+                    keep[k] = v
+                else:
+                    skipped += 1
             self.model.load_state_dict(keep, strict=False)
             print(f"Successfully loaded {len(keep)}/{len(state)} parameters")
+            if skipped:
+                print(f"Skipped {skipped} incompatible parameters")
+            missing = [k for k in own if k not in keep]
+            if missing:
+                print(f"Initialized {len(missing)} missing parameters with default values")
+                with torch.no_grad():
+                    for k in missing:                      # state_dict() tensors alias the parameters
+                        if "weight" in k:
+                            if own[k].dim() > 1:
+                                torch.nn.init.xavier_uniform_(own[k])
+                            else:
+                                torch.nn.init.normal_(own[k], 0, 0.01)
+                        elif "bias" in k:
+                            torch.nn.init.zeros_(own[k])
+                self.model.refresh_weights()
         except Exception as e:
             print(f"Error loading checkpoint: {e}")
             print("Continuing with randomly initialized weights...")
@@ -290,56 +319,168 @@ class CognitiveAimInference:
             raise ValueError("Number of instructions must match number of images")
         return self._run(list(image_paths), list(instructions), tolerate_errors=True)
 
-    def _run(self, paths: List[str], instructions: List[Optional[str]], tolerate_errors: bool = False) -> list:
-        import torch.distributed as dist
+    def _decode(self, path: str):
+        """Host part of loading one file (worker threads): decoded RGB bytes, EXIF, original size."""
         from PIL import Image
+        image = Image.open(path).convert("RGB")
+        return np.asarray(image, dtype=np.uint8), extract_exif(path), image.size
+
+    def _plan(self, idx: List[int], paths: List[str], instructions: List[Optional[str]]):
+        """Requests of this rank -> forward calls.  A file that is asked for with several instructions is decoded
+        once and its instructions go through ONE guided sweep (backbone and focal stream do not depend on the
+        instruction, reference src/model.py:1257); files with the same instruction list share batches.
+        Returns [(instruction tuple, [(path, [request index per instruction])])] in first-seen order."""
+        per_path: Dict[str, Dict[Optional[str], List[int]]] = {}
+        for i in idx:
+            per_path.setdefault(paths[i], {}).setdefault(instructions[i], []).append(i)
+        groups: Dict[tuple, list] = {}
+        for path, by_ins in per_path.items():
+            named = tuple(k for k in by_ins if k is not None)
+            if None in by_ins:
+                groups.setdefault((None,), []).append((path, [by_ins[None]]))
+            if named:
+                groups.setdefault(named, []).append((path, [by_ins[k] for k in named]))
+        return list(groups.items())
+
+    def _run(self, paths: List[str], instructions: List[Optional[str]], tolerate_errors: bool = False) -> list:
+        """The batch loop.  Files are decoded by a thread pool; a producer thread uploads the bytes and runs the
+        device preprocessing of chunk k+1 on a stream of its own, into one of three reused [B,3,H,W] buffers,
+        while chunk k runs the forward; depth / confidence rows travel to pinned host memory asynchronously and
+        are read one chunk later, so the loop has no per-chunk host-device synchronisation."""
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        import torch.distributed as dist
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         rank = dist.get_rank() if world > 1 else 0
         n = len(paths)
         lo, hi = shard_range(n, rank, world)
         results: List[Optional[tuple]] = [None] * n
         local = torch.full((hi - lo, 2), float("nan"))
-        loaded = []       # (global index, tensor, exif_raw, original size)
-        for i in range(lo, hi):
-            try:
-                image = Image.open(paths[i]).convert("RGB")
-                loaded.append((i, self.preprocess(image), extract_exif(paths[i]), image.size))
-            except Exception as e:
-                if not tolerate_errors:
-                    raise ValueError(f"Cannot load image {paths[i]}: {e}")
-                results[i] = (None, None, {"error": str(e)})
-        # group by instruction so that every forward is one homogeneous batch
-        groups: Dict[Optional[str], list] = {}
-        for item in loaded:
-            groups.setdefault(instructions[item[0]], []).append(item)
-        for instruction, items in groups.items():
-            for s in range(0, len(items), self.batch_size):
-                chunk = items[s: s + self.batch_size]
-                x = torch.stack([c[1] for c in chunk])
-                exif = {k: v.to(self.device) for k, v in exif_rows([c[2] for c in chunk], self.camera_to_id).items()}
-                if hasattr(self.model, "_last_attention_weights"):
-                    delattr(self.model, "_last_attention_weights")          # reference demo.py:334-335
-                if instruction is not None:
-                    depth, conf = self.model.forward_with_guidance(x, exif, instruction)
-                else:
-                    depth, conf = self.model(x, exif)
-                attn = self.model.get_attention_weights()
-                dc = torch.cat([depth, conf], dim=1).float().cpu()
-                heat = heatmap_postprocess(attn).cpu().numpy() if (attn is not None and self.render) else None
-                for j, (i, xt, exif_raw, orig_size) in enumerate(chunk):
-                    local[i - lo] = dc[j]
-                    meta = {"image_path": paths[i], "original_size": orig_size,
-                            "processed_size": tuple(xt.shape[1:]), "exif_available": exif_raw is not None,
-                            "exif_source": "real" if exif_raw is not None else "default", "instruction": instruction,
-                            "cognitive_modules": self.config.get("cognitive_modules", []),
-                            "model_status": {"ambient": self.model.use_ambient, "focal": self.model.use_focal,
-                                             "exif": self.model.use_exif},
-                            "exif_data": exif_raw or dict(DEFAULT_EXIF, Model="Default", Make="Default")}
-                    results[i] = (float(dc[j, 0]), float(dc[j, 1]), meta)
+        failure: List[BaseException] = []
+        try:
+            plan = self._plan(list(range(lo, hi)), paths, instructions)
+            H, W = self.image_size
+            chunks = []                      # (instruction tuple, [(path, request lists)])
+            for ins, files in plan:
+                per = self.batch_size if ins == (None,) or len(ins) == 1 else max(1, self.batch_size // len(ins))
+                chunks += [(ins, files[s: s + per]) for s in range(0, len(files), per)]
+            cap = max((len(c[1]) for c in chunks), default=1)
+            slots = [{"x": torch.empty(cap, 3, H, W, device=self.device), "free": None} for _ in range(3)]
+            ready: "queue.Queue" = queue.Queue(maxsize=2)
+            side = torch.cuda.Stream(device=self.device)
+
+            def produce():
+                try:
+                    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool:
+                        futs = [[pool.submit(self._decode, f[0]) for f in c[1]] for c in chunks]
+                        for ci, (ins, files) in enumerate(chunks):
+                            slot = slots[ci % 3]
+                            if slot["free"] is not None:
+                                slot["free"].synchronize()          # the forward that read this buffer has finished
+                            good = []
+                            with torch.cuda.stream(side):
+                                for (path, reqs), fut in zip(files, futs[ci]):
+                                    try:
+                                        arr, exif_raw, size = fut.result()
+                                        self.preprocess(arr, out=slot["x"][len(good)])
+                                        good.append((path, reqs, exif_raw, size))
+                                    except Exception as e:
+                                        if not tolerate_errors:
+                                            raise ValueError(f"Cannot load image {path}: {e}")
+                                        for r in reqs:
+                                            for i in r:
+                                                results[i] = (None, None, {"error": str(e)})
+                                ev = torch.cuda.Event()
+                                ev.record(side)
+                            ready.put((ins, slot, good, ev))
+                except BaseException as e:            # surfaces in the consumer
+                    failure.append(e)
+                finally:
+                    ready.put(None)
+
+            torch.cuda.set_device(self.device)
+            worker = threading.Thread(target=produce, daemon=True)
+            worker.start()
+            pending = None                     # previous chunk: its rows are read once the next one is queued
+
+            def finish(item):
+                ins, good, dc_host, ev, heat, K, imgs = item
+                ev.synchronize()
+                for j, (path, reqs, exif_raw, size) in enumerate(good):
+                    for k, name in enumerate(ins):
+                        d, c = float(dc_host[k, j, 0]), float(dc_host[k, j, 1])
+                        for i in reqs[k]:
+                            local[i - lo, 0], local[i - lo, 1] = d, c
+                            meta = {"image_path": paths[i], "original_size": size, "processed_size": (H, W),
+                                    "exif_available": exif_raw is not None,
+                                    "exif_source": "real" if exif_raw is not None else "default", "instruction": name,
+                                    "cognitive_modules": self.config.get("cognitive_modules", []),
+                                    "model_status": {"ambient": self.model.use_ambient, "focal": self.model.use_focal,
+                                                     "exif": self.model.use_exif},
+                                    "exif_data": exif_raw or dict(DEFAULT_EXIF, Model="Default", Make="Default")}
+                            results[i] = (d, c, meta)
+                            if self.render:
+                                try:
+                                    self._save_prediction_image(paths[i], imgs[j], d, c,
+                                                                None if heat is None else heat[k][j], name)
+                                except Exception as e:        # a failed drawing never costs the prediction
+                                    print(f"Prediction image skipped for {paths[i]}: {e}")
+
+            while True:
+                got = ready.get()
+                if got is None:
+                    break
+                ins, slot, good, ev = got
+                if good:
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ev)
+                    b = len(good)
+                    x = slot["x"][:b]
+                    exif = {k: v.to(self.device, non_blocking=True)
+                            for k, v in exif_rows([g[2] for g in good], self.camera_to_id).items()}
+                    if hasattr(self.model, "_last_attention_weights"):
+                        delattr(self.model, "_last_attention_weights")          # reference demo.py:334-335
+                    if ins == (None,):
+                        depth, conf = self.model(x, exif)
+                        attn = self.model.get_attention_weights()
+                        depth, conf = depth[None], conf[None]
+                        attn = None if attn is None else attn[None]
+                    elif len(ins) == 1:
+                        depth, conf = self.model.forward_with_guidance(x, exif, ins[0])
+                        attn = self.model.get_attention_weights()
+                        depth, conf = depth[None], conf[None]
+                        attn = None if attn is None else attn[None]
+                    else:
+                        depth, conf, attn = self.model.forward_with_guidance(x, exif, list(ins), return_attention=True)
+                    K = len(ins)
+                    dc_host = torch.empty(K, b, 2, dtype=torch.float32).pin_memory()
+                    dc_host.copy_(torch.cat([depth, conf], dim=2).float(), non_blocking=True)
+                    heat = imgs = None
                     if self.render:
-                        self._save_prediction_image(paths[i], xt, float(dc[j, 0]), float(dc[j, 1]),
-                                                    None if heat is None else heat[j], instruction)
-        self.model.synchronize()
+                        imgs = x.cpu()
+                        try:
+                            if attn is not None:
+                                hm = heatmap_postprocess(attn.reshape(K * b, -1)).cpu().numpy()
+                                heat = hm.reshape(K, b, hm.shape[-2], hm.shape[-1])
+                        except Exception as e:                # e.g. a grid beyond the heat-map kernel's limit
+                            print(f"Heat map skipped: {e}")
+                    done = torch.cuda.Event()
+                    done.record(cur)
+                    slot["free"] = done
+                    if pending is not None:
+                        finish(pending)
+                    pending = (ins, good, dc_host, done, heat, K, imgs)
+            if pending is not None:
+                finish(pending)
+            worker.join()
+            if failure:
+                raise failure[0]
+            self.model.synchronize()
+        except BaseException as e:
+            # under torch.distributed every rank must still reach the collective below; this rank's
+            # unfinished rows stay NaN there and the error is raised afterwards
+            failure.append(e)
         if world > 1:
             everyone = gather_shards(local.to(self.device), n).cpu()
             for i in range(n):
@@ -348,7 +489,31 @@ class CognitiveAimInference:
                                   {"image_path": paths[i], "instruction": instructions[i], "rank": "remote"})
                 elif results[i] is None:
                     results[i] = (None, None, {"error": "failed on a remote rank"})
+        if failure:
+            raise failure[0]
         return results
+
+    def save_results(self, results: list, output_path: str):
+        """Result list -> JSON file, reference demo.py:434-469 (which its own main() no longer calls, :686-687)."""
+        import json
+
+        def plain(o):
+            if isinstance(o, dict):
+                return {k: plain(v) for k, v in o.items()}
+            if isinstance(o, (list, tuple)):
+                return [plain(v) for v in o]
+            if hasattr(o, "numerator") and hasattr(o, "denominator") and not isinstance(o, (int, bool)):
+                return float(o.numerator) / float(o.denominator)
+            try:
+                json.dumps(o)
+                return o
+            except (TypeError, ValueError):
+                return str(o)
+        rows = [{"depth_value": None if d is None else float(d), "confidence_score": None if c is None else float(c),
+                 "metadata": plain(m)} for d, c, m in results]
+        with open(output_path, "w", encoding="utf-8") as f:
+            json.dump(rows, f, indent=2, ensure_ascii=False)
+        print(f"Results saved to: {output_path}")
 
     def _save_prediction_image(self, image_path, image_tensor, depth_value, confidence_score, grid, instruction):
         """Three-panel PNG of reference demo.py:471-600 (image | attention overlay | numbers); `grid` is the

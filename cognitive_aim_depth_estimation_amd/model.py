@@ -244,6 +244,11 @@ class CognitiveAimModel(nn.Module):
         # results do not depend on batch mates, so the outputs are bit-identical to a single-stream run.
         self.num_streams = max(1, int(config.get("streams", os.environ.get("COGAIM_STREAMS", "2"))))
         self._side_streams = None
+        # Opt-in: evaluate the curiosity module wherever the reference does (src/model.py:995, :1104, :1139, :1185),
+        # for the state it leaves behind -- exploration_history / history_pointer, get_exploration_stats() -- and for
+        # the draws it takes from torch's CPU generator (:609, :744), which fix where the guided path's per-call
+        # nn.Linear(768, 64) (:1417-1422) falls in the random stream.  Its score still reaches no output.
+        self.faithful_curiosity = bool(config.get("faithful_curiosity", False))
         # replay the per-shape launch sequence as one HIP graph after its first (eager) run
         self.use_graph = bool(config.get("use_hip_graph", os.environ.get("COGAIM_GRAPH", "1") != "0"))
 
@@ -690,9 +695,57 @@ class CognitiveAimModel(nn.Module):
     def get_attention_weights(self):
         return getattr(self, "_last_attention_weights", None)
 
-    def _forward_core(self, images, exif_data):
+    # ------------------------------------------------------------------ curiosity side effects (opt-in)
+    def _curiosity_draw(self, B):
+        """The two draws of one CuriosityModule.forward, in its order, from torch's CPU generator (the reference
+        run on a CPU draws there; src/model.py:609 then :744)."""
+        D = self.feature_dim
+        eps = torch.randn(B, D // 4)
+        noise = torch.randn(B, D) * 0.01
+        return eps, noise
+
+    def _curiosity_run(self, ws, B, draw):
+        """CuriosityModule.forward on the CLS tokens of ws['tokens'] (src/model.py:586-688, exif_data=None as at every
+        call site of the forward paths) + the ring-buffer update (:760-773), all on the device."""
+        D, T = self.feature_dim, ws["T"]
+        L, st = D // 4, stream_ptr()
+        dev = self._packed["device"]
+        cw = ws.get("curiosity")
+        if cw is None:
+            f32 = dict(device=dev, dtype=torch.float32)
+            cw = ws["curiosity"] = {k: torch.empty(B, n, **f32) for k, n in (
+                ("eps", L), ("noise", D), ("noisy", D), ("h384", D // 2), ("mu", L), ("logvar", L), ("z", L), ("rec", L),
+                ("h192", L), ("h128", 128), ("unc", 1), ("lb", 1), ("ln", 1), ("reward", 1))}
+        cw["eps"].copy_(draw[0]); cw["noise"].copy_(draw[1])
+        cls, ld = ws["tokens"].data_ptr(), T * D
+        c, lin, p = "curiosity_module.", self._linear, (lambda k: cw[k].data_ptr())
+        lin(cls, ld, c + "encoder_mean.0", p("h384"), D // 2, B, act=1)
+        lin(p("h384"), D // 2, c + "encoder_mean.3", p("mu"), L, B)
+        lin(cls, ld, c + "encoder_logvar.0", p("h384"), D // 2, B, act=1)
+        lin(p("h384"), D // 2, c + "encoder_logvar.3", p("logvar"), L, B)
+        call("cogaim_curiosity_sample", p("mu"), p("logvar"), p("eps"), p("z"), cls, ld, p("noise"), p("noisy"), B, L, D, st)
+        lin(p("z"), L, c + "decoder.0", p("h384"), D // 2, B, act=1)
+        lin(p("h384"), D // 2, c + "decoder.3", p("rec"), L, B)
+        lin(cls, ld, c + "uncertainty_head.0", p("h192"), L, B, act=1)
+        lin(p("h192"), L, c + "uncertainty_head.2", p("unc"), 1, B)
+        lin(cls, ld, c + "local_curiosity.0", p("h128"), 128, B, act=1)
+        lin(p("h128"), 128, c + "local_curiosity.2", p("lb"), 1, B)
+        lin(p("noisy"), D, c + "local_curiosity.0", p("h128"), 128, B, act=1)
+        lin(p("h128"), 128, c + "local_curiosity.2", p("ln"), 1, B)
+        hist, hp = self.curiosity_module.exploration_history, self.curiosity_module.history_pointer
+        if hist.device != dev or hp.device != dev or hist.dtype != torch.float32 or hp.dtype != torch.int64:
+            raise RuntimeError("curiosity buffers must live on the model's device (fp32 history, int64 pointer)")
+        call("cogaim_curiosity_finish", p("rec"), cls, ld, p("mu"), p("logvar"), p("unc"), p("lb"), p("ln"),
+             ptr(self._packed["f32"][c + "curiosity_weights"]), p("reward"), hist.data_ptr(), hp.data_ptr(), B, L,
+             hist.numel(), st)
+        return cw["reward"]
+
+    def _forward_core(self, images, exif_data, curiosity_calls=0):
         images, ws, B = self._prepare(images)
+        draws = [self._curiosity_draw(B) for _ in range(curiosity_calls)]
         self._features(images, exif_data, ws, B, graph_key="forward")
+        for dr in draws:
+            self._curiosity_run(ws, B, dr)
         depth, conf = self._outputs(ws)
         self._check_fallback_flags(ws)
         return depth, conf, (ws["attn"].clone() if self.use_focal else None), ws["fused"].clone()
@@ -722,10 +775,14 @@ class CognitiveAimModel(nn.Module):
         if images.dim() == 4 and images.shape[0] == 0:          # empty batch: empty results, nothing launched
             return self._empty_outputs(images, return_attention)
         n = min(self.num_streams, images.shape[0] // 8) if images.dim() == 4 and images.is_cuda else 1
+        calls = 0
+        if self.faithful_curiosity and self.use_focal:        # :995, :1104 (first call only), :1139
+            calls = 1 + int(not hasattr(self, "_last_attention_weights")) + int(bool(return_attention))
+            n = 1                                             # whole-batch draws, in the reference's order
         if n > 1:
             depth, conf, attn, fused = self._forward_split(images, exif_data, n)
         else:
-            depth, conf, attn, fused = self._forward_core(images, exif_data)
+            depth, conf, attn, fused = self._forward_core(images, exif_data, calls)
         self.fusion_features = fused
         if self.use_focal and not hasattr(self, "_last_attention_weights"):
             self._last_attention_weights = attn          # :1093-1113
@@ -769,6 +826,7 @@ class CognitiveAimModel(nn.Module):
             raise ValueError("attention_guidance cannot be resized to the patch grid")
         gkey = ("mask", attention_guidance.lower(), math.isqrt(N)) if isinstance(attention_guidance, str) else None
         gdev = self._table(*gkey) if gkey else g.to(self._packed["device"]).contiguous()
+        cdraw = self._curiosity_draw(B) if self.faithful_curiosity else None     # :1185, before the Linear of :1420
         if temp_projection is None:
             lin = nn.Linear(self.feature_dim, 64)
             temp_projection = (lin.weight.detach(), lin.bias.detach())
@@ -785,6 +843,8 @@ class CognitiveAimModel(nn.Module):
 
         ncols = self._features(images, exif_data, ws, B, focal_override=guided_focal,
                                graph_key=("guided", gdev.data_ptr()) if gkey else None)
+        if cdraw is not None:
+            self._curiosity_run(ws, B, cdraw)
         self._check_fallback_flags(ws)
         attn = ws["guided"].clone()
         self._last_attention_weights = attn                # :1212
@@ -834,7 +894,17 @@ class CognitiveAimModel(nn.Module):
                   "fused": torch.empty(K * B, 192, **f32), "out": torch.empty(2, K * B, **f32),
                   "pw": torch.empty(K, 64, D, **f32), "pb": torch.empty(K, 64, **f32)}
             ws["sweep"][K] = sw
-        for k, (w, b) in enumerate(self._projection_list(temp_projection, K, draw=True)):
+        given = self._projection_list(temp_projection, K, draw=False)
+        cdraws, pairs = [], []
+        for k in range(K):                 # the random stream of K single calls: curiosity draws (:1185), then the Linear
+            if self.faithful_curiosity:
+                cdraws.append(self._curiosity_draw(B))
+            if given[k] is None:
+                lin = nn.Linear(self.feature_dim, 64)
+                pairs.append((lin.weight.detach(), lin.bias.detach()))
+            else:
+                pairs.append(given[k])
+        for k, (w, b) in enumerate(pairs):
             sw["pw"][k].copy_(w.reshape(64, D), non_blocking=True)       # static buffers: the captured sequence
             sw["pb"][k].copy_(b.reshape(64), non_blocking=True)          # reads these addresses
         col_focal = []
@@ -858,6 +928,8 @@ class CognitiveAimModel(nn.Module):
 
         ncols = self._features(images, exif_data, ws, B, focal_override=col_focal.append, heads=False,
                                graph_key=("sweep", masks.data_ptr(), K) if mkey else None, tail=tail)
+        for dr in cdraws:
+            self._curiosity_run(ws, B, dr)
         self._check_fallback_flags(ws)
         attn = sw["guided"].clone()
         self._last_attention_weights = attn[K - 1]            # what the last of K single calls leaves (:1212)
@@ -897,7 +969,14 @@ class CognitiveAimModel(nn.Module):
         raise NotImplementedError("training is out of scope for this build")
 
     def get_exploration_stats(self):
-        return {"mean": 0.0, "std": 0.0, "max": 0.0, "samples": 0}
+        """Statistics of the positive entries of the exploration ring buffer (reference src/model.py:775-793, :1456-1460).
+        The buffer is only written in the opt-in ``faithful_curiosity`` mode (or by a loaded checkpoint)."""
+        hist = self.curiosity_module.exploration_history.detach().float().cpu()
+        valid = hist[hist > 0]
+        if valid.numel() == 0:
+            return {"mean": 0.0, "std": 0.0, "max": 0.0, "samples": 0}
+        return {"mean": float(valid.mean()), "std": float(valid.std()) if valid.numel() > 1 else 0.0,
+                "max": float(valid.max()), "min": float(valid.min()), "samples": int(valid.numel())}
 
 
 def create_model(config, camera_info=None, device=None):

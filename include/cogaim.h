@@ -179,6 +179,20 @@ int cogaim_exif_prep(const long long* camera_idx, const float* focal_length, con
 int cogaim_heads(const float* fused, int K, const float* wd, const float* bd, const float* wc, const float* bc,
                  const float* w2, const float* b2, float* depth, float* conf, int B, void* stream);
 
+/* Curiosity module (src/model.py:586-773), the parts that are not plain Linear layers.  Its score never
+ * reaches depth or confidence; it is evaluated only in the opt-in faithful mode, for the state it leaves behind
+ * (exploration_history ring buffer, history_pointer) and the random draws it consumes.
+ * sample: z = mu + eps * exp(logvar / 2) [B,L] (:608-610) and noisy = cls + noise [B,D] (:743-745); the draws
+ * eps, noise are the caller's.  finish: reconstruction error ("robust", :620-623), KL term (:635), softplus
+ * uncertainty head (:638-643), local term with its sensitivity (:738-758), geometric term 0.5 (no EXIF, :698-700),
+ * softmax(weights3) mix (:666-671) -> reward [B]; then history[(pointer + i) % hist_len] = reward[i] in image
+ * order and pointer += B mod hist_len (:769-773), unless history / pointer are NULL. */
+int cogaim_curiosity_sample(const float* mu, const float* logvar, const float* eps, float* z, const float* cls,
+                            long long ld_cls, const float* noise, float* noisy, int B, int L, int D, void* stream);
+int cogaim_curiosity_finish(const float* rec, const float* cls, long long ld_cls, const float* mu, const float* logvar,
+                            const float* unc_pre, const float* lb_pre, const float* ln_pre, const float* weights3,
+                            float* reward, float* history, long long* pointer, int B, int L, int hist_len, void* stream);
+
 /* demo.py:533-552 (the attention map as it is drawn): per image, weights cubed, those at or below their 70th
  * percentile (numpy's default linear interpolation) multiplied by 0.3, min-max rescaled with the reference's
  * 1e-8 in the denominator, laid out on the G x G grid (G = ceil(sqrt(N)), zero padded when N is not a square).

@@ -229,6 +229,30 @@ def exif_prior(sd: SD, exif: Dict[str, Tensor], prefix: str = "exif_prior.") -> 
     return _lin(sd, prefix + "fusion.3", h)
 
 
+def curiosity_reward(sd: SD, cls: Tensor, eps: Tensor, noise: Tensor, prefix: str = "curiosity_module.") -> Tensor:
+    """model.py:586-688 as called from the forward paths (features = CLS token, exif_data=None, loss_type
+    "robust", uncertainty_weight 0.1), with the two random draws (:609 ``eps`` [B,192], :744 ``noise`` [B,768],
+    already scaled by 0.01) passed in.  Returns the reward that :680 writes to the exploration history (before
+    the final clamp of :685)."""
+    def seq(name, x, last_act=None):
+        i0, i1 = (("0", "3") if name in ("encoder_mean", "encoder_logvar", "decoder") else ("0", "2"))
+        return _lin(sd, f"{prefix}{name}.{i1}", F.relu(_lin(sd, f"{prefix}{name}.{i0}", x)))
+    mu, logvar = seq("encoder_mean", cls), seq("encoder_logvar", cls)
+    z = mu + eps * torch.exp(0.5 * logvar)                                   # :608-610
+    rec = seq("decoder", z)
+    diff = rec - cls[:, :rec.size(1)]
+    re = torch.sqrt(torch.sum(diff ** 2, dim=1) + 1e-8)                      # :621-623
+    re = (re / (1.0 + re)).clamp(min=0.0)
+    kl = (-0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp(), dim=1)).clamp(min=0.0)   # :635, :642
+    unc = F.softplus(seq("uncertainty_head", cls)).squeeze(-1).clamp(0.0, 10.0)            # :638, :643
+    basic = re + 0.1 * kl + 0.1 * unc                                        # :646
+    lb = torch.sigmoid(seq("local_curiosity", cls)).squeeze(-1)              # :738
+    ln = torch.sigmoid(seq("local_curiosity", cls + noise)).squeeze(-1)      # :745-748
+    local = (lb + (lb - ln).abs() * 0.2).clamp(0.0, 1.0)                     # :751-758
+    w = torch.softmax(sd[prefix + "curiosity_weights"], dim=0)               # :666
+    return w[0] * 0.5 + w[1] * local + w[2] * basic                          # :669-671, geometric = 0.5 (:698-700)
+
+
 def fusion_and_heads(sd: SD, feats: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     """model.py:908-912 (fusion), :925-928 (depth: Linear+Softplus),
     :936-941 (confidence: Linear, ReLU, Linear(1,1), Sigmoid)."""

@@ -251,6 +251,62 @@ def g7_full_model(ref):
     save("g7_full_model", **arrays)
 
 
+def g8_curiosity_state(ref):
+    """State the curiosity module leaves behind (src/model.py:760-773, :775-793) and where the guided path's
+    per-call Linear falls in torch's CPU random stream (:609, :744, :1417-1422), over a fixed call sequence
+    under one seed.  Same model and weights as g7 'full'; the ring pointer starts at 997 so that it wraps."""
+    from transformers import Dinov2Config, Dinov2Model
+    layers, grid = 2, 4
+    ref.Dinov2Model.from_pretrained = classmethod(
+        lambda cls, name, *a, **k: Dinov2Model(Dinov2Config(image_size=14 * grid, num_hidden_layers=layers)))
+    cfg = {"cognitive_modules": ["ambient_stream", "iterative_focal_stream", "exif_prior_database"],
+           "focal_config": {"num_iterations": 3, "focus_strength": 1.5}}
+    with quiet():
+        model = ref.create_model(cfg, {"num_cameras": 71}).eval()
+    spec = reference_state_spec(layers=layers, native_grid=grid, num_iterations=3, num_cameras=71)
+    model.load_state_dict(synth_state_dict(spec, seed=7), strict=True)
+    model.curiosity_module.history_pointer.fill_(997)
+    g = torch.Generator().manual_seed(31)
+    x56, x70 = torch.randn(3, 3, 56, 56, generator=g), torch.randn(2, 3, 70, 70, generator=g)
+    exif = {"camera_idx": torch.tensor([0, 5, 70]), "focal_length": torch.tensor([50.0, 24.0, 135.0]),
+            "aperture": torch.tensor([2.8, 8.0, 1.8]), "iso": torch.tensor([100.0, 1600.0, 400.0])}
+    arrays = {"layers": layers, "native_grid": grid, "seed": 7, "torch_seed": 4242, "pointer0": 997,
+              "x56": x56.numpy(), "x70": x70.numpy()}
+    for k, v in exif.items():
+        arrays["exif:" + k] = v.numpy()
+    created = []
+    real_linear = ref.nn.Linear
+
+    class Spy(real_linear):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            created.append(self)
+
+    def snap(tag, out):
+        arrays[tag + ":history"] = model.curiosity_module.exploration_history.numpy().copy()
+        arrays[tag + ":pointer"] = int(model.curiosity_module.history_pointer)
+        st = model.get_exploration_stats()
+        arrays[tag + ":stats"] = np.array([st["mean"], st["std"], st["max"], st.get("min", 0.0), st["samples"]])
+        arrays[tag + ":depth"], arrays[tag + ":conf"] = out[0].numpy(), out[1].numpy()
+
+    torch.manual_seed(4242)
+    ref.nn.Linear = Spy
+    try:
+        with torch.no_grad(), quiet() as log:
+            snap("a", model(x56, exif))                                   # fresh: 2 curiosity calls
+            snap("b", model(x56, exif, return_attention=True))            # attribute set: 1 + 1 calls
+            snap("c", model.forward_with_guidance(x56, exif, "left"))     # 1 call, then the Linear
+            snap("d", model(x70, None))                                   # 1 call
+            snap("e", model.forward_with_guidance(x56, exif, "top-right"))
+    finally:
+        ref.nn.Linear = real_linear
+    assert "failed" not in log.getvalue(), log.getvalue()
+    assert len(created) == 2
+    for tag, lin in zip("ce", created):
+        arrays[tag + ":proj_w"], arrays[tag + ":proj_b"] = lin.weight.detach().numpy(), lin.bias.detach().numpy()
+    save("g8_curiosity_state", **arrays)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
@@ -260,6 +316,7 @@ def main():
     g5_guidance(ref)
     g6_pe_table(ref)
     g7_full_model(ref)
+    g8_curiosity_state(ref)
 
 
 if __name__ == "__main__":

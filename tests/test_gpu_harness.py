@@ -82,3 +82,48 @@ def test_guided_batch_and_rendering(workdir):
     out = sorted(os.listdir("demo_results"))
     assert out == ["img0_center_prediction.png", "img1_prediction.png", "img2_top-left_prediction.png"]
     assert all(os.path.getsize(os.path.join("demo_results", f)) > 10_000 for f in out)
+
+
+def test_instruction_sweep_through_the_harness(workdir, monkeypatch):
+    """BASELINE config 3 through predict_batch: one file asked for with the nine instructions is decoded once and
+    goes through ONE guided forward (one backbone + focal pass); the heat maps of the sweep equal those of nine
+    single calls bit for bit, and files with real EXIF feed their own values to the model."""
+    from PIL import Image
+    from PIL.TiffImagePlugin import IFDRational
+    paths, cfg, ckpt, sd = workdir
+    h = inf.CognitiveAimInference(cfg, ckpt, device="cuda", batch_size=8, render=False)
+    calls = []
+    real = h.model.forward_with_guidance
+
+    def spy(images, exif_data=None, attention_guidance=None, *a, **k):
+        calls.append((tuple(images.shape), attention_guidance))
+        return real(images, exif_data, attention_guidance, *a, **k)
+    monkeypatch.setattr(h.model, "forward_with_guidance", spy)
+    names = list(O.INSTRUCTIONS)
+    res = h.predict_batch([paths[0]] * 9 + [paths[1]], names + [None])
+    assert len(calls) == 1 and calls[0][0][0] == 1 and list(calls[0][1]) == names
+    assert [r[2]["instruction"] for r in res] == names + [None]
+    assert all(np.isfinite(r[0]) and 0 < r[1] < 1 for r in res)
+    x = h.preprocess(PIL.open(paths[0]))[None]
+    exif = {k: v.cuda() for k, v in inf.exif_rows([None], h.camera_to_id).items()}
+    _, _, sweep = real(x, exif, names, return_attention=True)
+    for k, name in enumerate(names):
+        _, _, one = real(x, exif, name, return_attention=True)
+        assert torch.equal(one, sweep[k]), name
+    # EXIF read from the file reaches the forward: same prediction as the oracle with those values
+    ex = Image.Exif()
+    ex[0x010F], ex[0x0110] = "Canon", "EOS R5"
+    ifd = ex.get_ifd(0x8769)
+    ifd[0x920A], ifd[0x829D], ifd[0x8827] = IFDRational(85, 1), IFDRational(18, 10), 800
+    p = os.path.join(os.path.dirname(paths[0]), "with_exif.jpg")
+    PIL.open(paths[2]).save(p, exif=ex, quality=95)
+    h.camera_to_id["EOS R5"] = 12
+    d, c, meta = h.predict(p)
+    assert meta["exif_source"] == "real" and meta["exif_data"]["FocalLength"] == 85.0
+    xo = inf.preprocess_image(PIL.open(p).convert("RGB"), (SIZE, SIZE))[None]
+    rows = inf.exif_rows([inf.extract_exif(p)], h.camera_to_id)
+    assert rows["camera_idx"].tolist() == [12]
+    d_ref, c_ref = O.forward(sd, xo, rows)
+    assert rel_err(torch.tensor([[d]]), d_ref) <= 1e-3 and rel_err(torch.tensor([[c]]), c_ref) <= 1e-3
+    d_def, _, _ = h.predict(paths[2])
+    assert abs(d_def - d) > 1e-6                               # the EXIF values matter

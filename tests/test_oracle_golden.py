@@ -143,3 +143,28 @@ def test_full_model_variants(golden_dir):
     close(d, z["it2:56:depth"], rtol=1e-4)
     close(c, z["it2:56:conf"], rtol=1e-4)
     close(a, z["it2:56:attn"], rtol=1e-3, atol=1e-8)
+
+
+def test_curiosity_reward_and_ring_buffer_vs_reference():
+    """oracle.curiosity_reward + the ring-buffer rule (src/model.py:760-773) reproduce the exploration history the
+    real reference left after its first forward (tests/golden/g8_curiosity_state.npz, call 'a': two curiosity
+    evaluations of 3 images, pointer starting at 997)."""
+    import numpy as np
+    import torch
+    from oracle import cogaim_oracle as O
+    from oracle.weights import reference_state_spec, synth_state_dict
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_curiosity_state.npz"))
+    sd = synth_state_dict(reference_state_spec(layers=int(z["layers"]), native_grid=int(z["native_grid"])), seed=int(z["seed"]))
+    x = torch.from_numpy(z["x56"])
+    with torch.no_grad():
+        cls = O.dinov2_forward(sd, x)[:, 0]
+        torch.manual_seed(int(z["torch_seed"]))
+        hist, ptr_ = np.zeros(1000, np.float32), int(z["pointer0"])
+        for _ in range(2):
+            eps = torch.randn(3, 192)
+            noise = torch.randn(3, 768) * 0.01
+            for r in O.curiosity_reward(sd, cls, eps, noise).tolist():
+                hist[ptr_ % 1000] = r
+                ptr_ = (ptr_ + 1) % 1000
+    assert ptr_ == int(z["a:pointer"])
+    assert np.allclose(hist, z["a:history"], rtol=1e-5, atol=1e-7), float(np.abs(hist - z["a:history"]).max())
