@@ -123,14 +123,63 @@ class DevicePreprocessor:
         return out
 
 
-def extract_exif(image_path: str) -> Optional[Dict]:
-    """reference demo.py:170-255: FocalLength / FNumber / ExposureTime / ISO with range checks, Make / Model."""
+def _preprocess_batch(self, arrays, out: torch.Tensor) -> torch.Tensor:
+    """Several decoded images in one go: their bytes are packed into a pinned staging buffer (two, used in turn),
+    cross to the device in ONE asynchronous copy on the current stream, and the resize / normalise kernel runs once
+    per image on its slice.  arrays: uint8 [h, w, 3] each (sizes may differ); out: fp32 [len(arrays), 3, H, W]."""
+    from ._lib import call, ptr, stream_ptr
+    H, W = self.size
+    if out.shape[1:] != (3, H, W) or out.shape[0] < len(arrays) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("out must be a contiguous fp32 [n, 3, H, W] tensor")
+    offs, total = [], 0
+    for a in arrays:
+        if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
+            raise ValueError(f"expected uint8 RGB arrays, got {a.dtype} {a.shape}")
+        offs.append(total)
+        total += (a.size + 255) // 256 * 256
+    st = getattr(self, "_stage", None)
+    if st is None:
+        st = self._stage = {"turn": 0, "pinned": [None, None], "event": [None, None], "dev": None}
+    t = st["turn"] = 1 - st["turn"]
+    if st["pinned"][t] is None or st["pinned"][t].numel() < total:
+        st["pinned"][t] = torch.empty(max(total, 1 << 20), dtype=torch.uint8).pin_memory()
+        st["event"][t] = None
+    if st["event"][t] is not None:
+        st["event"][t].synchronize()             # the copy that last read this staging buffer has finished
+    if st["dev"] is None or st["dev"].numel() < total:
+        st["dev"] = torch.empty(max(total, 1 << 20), dtype=torch.uint8, device=self.device)
+    host = st["pinned"][t].numpy()
+    for a, o in zip(arrays, offs):
+        np.copyto(host[o: o + a.size].reshape(a.shape), a)
+    st["dev"][:total].copy_(st["pinned"][t][:total], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    st["event"][t] = ev
+    need = max((a.shape[0] for a in arrays), default=0) * W * 3
+    if self._tmp is None or self._tmp.numel() < need:
+        self._tmp = torch.empty(need, dtype=torch.uint8, device=self.device)
+    base = st["dev"].data_ptr()
+    for j, (a, o) in enumerate(zip(arrays, offs)):
+        h, w = int(a.shape[0]), int(a.shape[1])
+        xb, xc, xk = self._axis_tables(w, W)
+        yb, yc, yk = self._axis_tables(h, H)
+        call("cogaim_preprocess_rgb8", base + o, h, w, w * 3, ptr(xb), ptr(xc), xk, ptr(yb), ptr(yc), yk,
+             ptr(self._tmp), ptr(self._lut), out[j].data_ptr(), H, W, stream_ptr())
+    return out
+
+
+DevicePreprocessor.batch = _preprocess_batch
+
+
+def extract_exif(image_path) -> Optional[Dict]:
+    """reference demo.py:170-255: FocalLength / FNumber / ExposureTime / ISO with range checks, Make / Model.
+    Takes a path or an already opened PIL image (the batch loop opens every file once)."""
     try:
         from PIL import Image
         from PIL.ExifTags import TAGS
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            image = Image.open(image_path)
+            image = Image.open(image_path) if isinstance(image_path, (str, os.PathLike)) else image_path
             try:
                 raw = image._getexif()
             except Exception:
@@ -322,8 +371,10 @@ class CognitiveAimInference:
     def _decode(self, path: str):
         """Host part of loading one file (worker threads): decoded RGB bytes, EXIF, original size."""
         from PIL import Image
-        image = Image.open(path).convert("RGB")
-        return np.asarray(image, dtype=np.uint8), extract_exif(path), image.size
+        opened = Image.open(path)
+        exif_raw = extract_exif(opened)              # before convert(): the converted copy carries no EXIF
+        image = opened.convert("RGB")
+        return np.asarray(image, dtype=np.uint8), exif_raw, image.size
 
     def _plan(self, idx: List[int], paths: List[str], instructions: List[Optional[str]]):
         """Requests of this rank -> forward calls.  A file that is asked for with several instructions is decoded
@@ -370,30 +421,49 @@ class CognitiveAimInference:
             ready: "queue.Queue" = queue.Queue(maxsize=2)
             side = torch.cuda.Stream(device=self.device)
 
+            timing = {"producer_wait_decode_s": 0.0, "producer_upload_preprocess_s": 0.0, "producer_wait_buffer_s": 0.0,
+                      "consumer_wait_chunk_s": 0.0, "consumer_forward_issue_s": 0.0, "consumer_results_s": 0.0}
+            self.last_timing = timing
+            clock = __import__("time").perf_counter
+
             def produce():
                 try:
                     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool:
                         futs = [[pool.submit(self._decode, f[0]) for f in c[1]] for c in chunks]
                         for ci, (ins, files) in enumerate(chunks):
                             slot = slots[ci % 3]
+                            t0 = clock()
                             if slot["free"] is not None:
                                 slot["free"].synchronize()          # the forward that read this buffer has finished
-                            good = []
+                            timing["producer_wait_buffer_s"] += clock() - t0
+                            good, arrays = [], []
+                            t0 = clock()
+                            for (path, reqs), fut in zip(files, futs[ci]):
+                                try:
+                                    arr, exif_raw, size = fut.result()
+                                    arrays.append(arr)
+                                    good.append((path, reqs, exif_raw, size))
+                                except Exception as e:
+                                    if not tolerate_errors:
+                                        raise ValueError(f"Cannot load image {path}: {e}")
+                                    for r in reqs:
+                                        for i in r:
+                                            results[i] = (None, None, {"error": str(e)})
+                            t1 = clock()
                             with torch.cuda.stream(side):
-                                for (path, reqs), fut in zip(files, futs[ci]):
-                                    try:
-                                        arr, exif_raw, size = fut.result()
-                                        self.preprocess(arr, out=slot["x"][len(good)])
-                                        good.append((path, reqs, exif_raw, size))
-                                    except Exception as e:
-                                        if not tolerate_errors:
-                                            raise ValueError(f"Cannot load image {path}: {e}")
-                                        for r in reqs:
-                                            for i in r:
-                                                results[i] = (None, None, {"error": str(e)})
+                                exif = None
+                                if arrays:
+                                    self.preprocess.batch(arrays, slot["x"])
+                                    # uploaded here, not by the consumer: a copy from pageable memory makes the host
+                                    # wait for everything queued before it on its stream -- on the forward's stream
+                                    # that is the previous chunk's whole forward
+                                    exif = {k: v.to(self.device) for k, v in
+                                            exif_rows([g[2] for g in good], self.camera_to_id).items()}
                                 ev = torch.cuda.Event()
                                 ev.record(side)
-                            ready.put((ins, slot, good, ev))
+                            timing["producer_wait_decode_s"] += t1 - t0
+                            timing["producer_upload_preprocess_s"] += clock() - t1
+                            ready.put((ins, slot, good, ev, exif))
                 except BaseException as e:            # surfaces in the consumer
                     failure.append(e)
                 finally:
@@ -428,17 +498,20 @@ class CognitiveAimInference:
                                     print(f"Prediction image skipped for {paths[i]}: {e}")
 
             while True:
+                t0 = clock()
                 got = ready.get()
+                timing["consumer_wait_chunk_s"] += clock() - t0
                 if got is None:
                     break
-                ins, slot, good, ev = got
+                ins, slot, good, ev, exif = got
+                t0 = clock()
                 if good:
                     cur = torch.cuda.current_stream(self.device)
                     cur.wait_event(ev)
                     b = len(good)
                     x = slot["x"][:b]
-                    exif = {k: v.to(self.device, non_blocking=True)
-                            for k, v in exif_rows([g[2] for g in good], self.camera_to_id).items()}
+                    for v in exif.values():
+                        v.record_stream(cur)
                     if hasattr(self.model, "_last_attention_weights"):
                         delattr(self.model, "_last_attention_weights")          # reference demo.py:334-335
                     if ins == (None,):
@@ -468,8 +541,11 @@ class CognitiveAimInference:
                     done = torch.cuda.Event()
                     done.record(cur)
                     slot["free"] = done
+                    timing["consumer_forward_issue_s"] += clock() - t0
+                    t0 = clock()
                     if pending is not None:
                         finish(pending)
+                    timing["consumer_results_s"] += clock() - t0
                     pending = (ins, good, dc_host, done, heat, K, imgs)
             if pending is not None:
                 finish(pending)
