@@ -52,6 +52,10 @@ def gemm_flops(name, args):
     elif name == "cogaim_gemm_batched_f32":
         M, N, K, batch = args[3], args[4], args[5], args[12]
         return 2.0 * M * N * K * batch, (M, N, K, batch)
+    elif name in ("cogaim_focal_scores_rowstats", "cogaim_focal_scores_colsum"):
+        i0 = 4 if name.endswith("rowstats") else 6
+        N, D, batch = args[i0], args[i0 + 1], args[i0 + 4]
+        return 2.0 * N * N * D * batch, (N, N, D, batch)
     elif name == "cogaim_gemm_patch_embed":
         M, N, K = args[5] * args[6], args[7], args[8]
     elif name == "cogaim_mhsa_qkv_fwd":

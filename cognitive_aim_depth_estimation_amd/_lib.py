@@ -33,10 +33,15 @@ SIGNATURES = {
     "cogaim_gemm_batched_f32": [P, P, P, I, I, I, I, I, I, LL, LL, LL, I, I, P],
     "cogaim_focal_colsum_rows": [],
     "cogaim_focal_softmax_stats_colsum": [P, I, LL, P, P, P, I, I, P],
-    "cogaim_focal_attention_vector": [P, P, P, P, P, P, F, I, I, P],
+    "cogaim_focal_attention_vector": [P, P, P, P, P, P, F, I, I, I, P],
     "cogaim_focal_var_flag": [P, I, I, P, I, P],
     "cogaim_focal_weighted_colsum": [P, I, LL, P, P, P, P, I, I, P],
-    "cogaim_focal_reduce_u": [P, P, P, I, I, P],
+    "cogaim_focal_reduce_u": [P, P, P, I, I, I, P],
+    "cogaim_focal_rowstats_parts": [I],
+    "cogaim_focal_scores_colsum_blocks": [I],
+    "cogaim_focal_scores_rowstats": [P, P, P, P, I, I, I, LL, I, I, P],
+    "cogaim_focal_rowstats_combine": [P, P, I, P, P, I, I, P],
+    "cogaim_focal_scores_colsum": [P, P, P, P, P, P, I, I, I, LL, I, I, P],
     "cogaim_weighted_tokens_rows": [],
     "cogaim_weighted_tokens": [P, LL, P, P, P, P, P, I, I, I, P],
     "cogaim_weighted_tokens_static": [P, LL, P, P, P, P, I, I, I, P],
@@ -51,7 +56,8 @@ SIGNATURES = {
     "cogaim_curiosity_finish": [P, P, LL, P, P, P, P, P, P, P, P, P, I, I, I, P],
 }
 
-_NO_STATUS = {"cogaim_version", "cogaim_gemm_workspace_bytes", "cogaim_focal_colsum_rows", "cogaim_weighted_tokens_rows"}
+_NO_STATUS = {"cogaim_version", "cogaim_gemm_workspace_bytes", "cogaim_focal_colsum_rows", "cogaim_weighted_tokens_rows",
+              "cogaim_focal_rowstats_parts", "cogaim_focal_scores_colsum_blocks"}
 _lib = None
 
 

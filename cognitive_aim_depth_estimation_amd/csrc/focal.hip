@@ -220,6 +220,21 @@ __global__ __launch_bounds__(256) void focal_stats_colsum_rows_kernel(const floa
         (r[c] + r[NCH * 256 + c]) + (r[2 * NCH * 256 + c] + r[3 * NCH * 256 + c]);
 }
 
+// rmax[r] = max_p pmax[r][p];  rinv[r] = 1 / sum_p psum[r][p] exp2(pmax[r][p] - rmax[r])     (r over B*N rows)
+__global__ __launch_bounds__(256) void rowstats_combine_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
+                                                               int parts, float* __restrict__ rmax, float* __restrict__ rinv,
+                                                               long long rows) {
+  const long long r = blockIdx.x * 256LL + threadIdx.x;
+  if (r >= rows) return;
+  const float* pm = pmax + r * parts;
+  const float* pl = psum + r * parts;
+  float m = -INFINITY;
+  for (int p = 0; p < parts; ++p) m = fmaxf(m, pm[p]);
+  float l = 0.f;
+  for (int p = 0; p < parts; ++p) l += pl[p] * __builtin_amdgcn_exp2f(pm[p] - m);      // parts ascending: fixed order
+  rmax[r] = m; rinv[r] = 1.0f / l;
+}
+
 // colsum[b][c] = sum_blk part[b][blk][c]      (wide grid: one thread per column)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nblk,
                                                               float* __restrict__ out, int N) {
@@ -398,9 +413,9 @@ int cogaim_focal_weighted_colsum(const float* S, int ldS, long long strideS, con
 // scale_out = scale_in * (1 + focus_strength * a) when scale_out != NULL (scale_in NULL = ones).
 int cogaim_focal_attention_vector(const float* part, const float* center_bias, float* a, double* stats,
                                   const float* scale_in, float* scale_out, float focus_strength, int B, int N,
-                                  void* stream) {
+                                  int nblk, void* stream) {
   if (B <= 0 || N <= 0) return COGAIM_EINVAL;
-  const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
+  if (nblk <= 0) nblk = (N + CS_ROWS - 1) / CS_ROWS;
   // the reduced column sums are staged in `a` itself (the kernel reads a[b][c] before overwriting it)
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, part, nblk, a, N);
   hipLaunchKernelGGL(focal_attention_vector_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)a,
@@ -414,11 +429,21 @@ int cogaim_focal_var_flag(const double* stats, int B, int N, int* flags, int slo
   return COGAIM_LAUNCH_CHECK();
 }
 
-int cogaim_focal_reduce_u(const float* part, float* u, float* usum, int B, int N, void* stream) {
+int cogaim_focal_reduce_u(const float* part, float* u, float* usum, int B, int N, int nblk, void* stream) {
   if (B <= 0 || N <= 0) return COGAIM_EINVAL;
-  const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
+  if (nblk <= 0) nblk = (N + CS_ROWS - 1) / CS_ROWS;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, part, nblk, u, N);
   hipLaunchKernelGGL(row_sum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)u, usum, N);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+// Row statistics from the per-strip partials of cogaim_focal_scores_rowstats: pmax / psum [B*N][parts] -> rmax / rinv [B*N]
+int cogaim_focal_rowstats_combine(const float* pmax, const float* psum, int parts, float* rmax, float* rinv, int B, int N,
+                                  void* stream) {
+  if (B <= 0 || N <= 0 || parts <= 0) return COGAIM_EINVAL;
+  const long long rows = (long long)B * N;
+  hipLaunchKernelGGL(rowstats_combine_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pmax,
+                     psum, parts, rmax, rinv, rows);
   return COGAIM_LAUNCH_CHECK();
 }
 

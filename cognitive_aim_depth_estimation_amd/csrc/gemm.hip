@@ -108,6 +108,7 @@ __device__ __forceinline__ float4 ldg4(const float* base, size_t off, bool ok) {
 }
 
 template <class T> struct EpiBiasHalf {           // out16 = (acc + bias) [* scale for n < scale_cols]
+  static constexpr int kReduce = 0;   // 1 / 2: the tile is reduced in registers instead of stored (EpiRowStats / EpiColSum)
   static constexpr bool kWide = true, kResidual = false;
   static constexpr int kColVecs = 1;   // per-column vectors load_cols fills: 0 none, 1 bias, 2 bias and scale
   T* out; const float* bias; int ldc; int scale_cols; float scale; int M, N; int* range_flag;
@@ -185,6 +186,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 template <class T> struct EpiBiasGeluHalf {
+  static constexpr int kReduce = 0;   // 1 / 2: the tile is reduced in registers instead of stored (EpiRowStats / EpiColSum)
   static constexpr bool kWide = true, kResidual = false;
   static constexpr int kColVecs = 1;   // per-column vectors load_cols fills: 0 none, 1 bias, 2 bias and scale
   T* out; const float* bias; int ldc; int M, N; int* range_flag;
@@ -238,6 +240,7 @@ template <class T> struct EpiBiasGeluHalf {
 };
 
 struct EpiResidualF32 {                            // x += (acc + bias) * layerscale   (in place)
+  static constexpr int kReduce = 0;   // 1 / 2: the tile is reduced in registers instead of stored (EpiRowStats / EpiColSum)
   static constexpr bool kWide = false, kResidual = true;
   static constexpr int kColVecs = 2;   // per-column vectors load_cols fills: 0 none, 1 bias, 2 bias and scale
   float* x; const float* bias; const float* ls; int ldc; int M, N;
@@ -260,6 +263,7 @@ struct EpiResidualF32 {                            // x += (acc + bias) * layers
 };
 
 struct EpiStoreF32 {                               // batched plain fp32 store (focal scores)
+  static constexpr int kReduce = 0;   // 1 / 2: the tile is reduced in registers instead of stored (EpiRowStats / EpiColSum)
   static constexpr bool kWide = false, kResidual = false;
   static constexpr int kColVecs = 0;   // per-column vectors load_cols fills: 0 none, 1 bias, 2 bias and scale
   float* out; int ldc; long long strideC; int M, N;
@@ -276,6 +280,7 @@ struct EpiStoreF32 {                               // batched plain fp32 store (
 };
 
 struct EpiPatchEmbed {                             // token row b*T+1+p = acc + bias + pos[1+p]
+  static constexpr int kReduce = 0;   // 1 / 2: the tile is reduced in registers instead of stored (EpiRowStats / EpiColSum)
   static constexpr bool kWide = false, kResidual = true;
   static constexpr int kColVecs = 1;   // per-column vectors load_cols fills: 0 none, 1 bias, 2 bias and scale
   float* x; const float* bias; const float* pos; int D; int P; int M;   // P patches per image
@@ -293,6 +298,100 @@ struct EpiPatchEmbed {                             // token row b*T+1+p = acc + 
   }
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
     float4 b, l; load_cols(n0, b, l); float pk = 0.f; finish4n(0, m, n0, v, b, b, load_res(0, m, n0), pk);
+  }
+};
+
+// Focal scores that are never stored (large grids).  Both epilogues see a whole 256x256 tile of
+// S = Y X~^T (log2 domain) in the accumulators of the persistent kernel and reduce it there:
+//   EpiRowStats: per row and per 64-column wave strip, max and sum of exp2(S - max)   -> pmax / psum [z][row][part]
+//   EpiColSum:   per column, sum over the tile half's 128 rows of w_n exp2(S - m_n) / l_n -> part [z][block][col]
+// The element-wise hooks below exist only because the shared kernels name them; these epilogues run on
+// whole tiles of the persistent kernel only (no K-split, no quadrant items, no 128x128 kernel).
+struct EpiRowStats {
+  static constexpr int kReduce = 1;
+  static constexpr bool kWide = false, kResidual = false;
+  static constexpr int kColVecs = 0;
+  float* pmax; float* psum; int parts; int M, N;      // parts = 4 * column tiles; arrays [z][M][parts]
+  __device__ __forceinline__ void load_cols(int, float4&, float4&) const {}
+  __device__ __forceinline__ float4 load_res(int, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ void flush_peak(float) const {}
+  __device__ __forceinline__ void finish4n(int, int, int, f32x4, float4, float4, float4, float&) const {}
+  __device__ __forceinline__ void store4n(int, int, int, f32x4) const {}
+  // acc: the wave's 128 x 64 accumulators; rows m_base + 16 i + fr, columns n_base + 16 jj + 4 fq + e
+  __device__ __forceinline__ void reduce_tile(int z, int m_base, int n_base, int part_idx, const f32x4 (&acc)[8][4],
+                                              int fr, int fq) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v[16];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[4 * jj + e] = (n_base + 16 * jj + 4 * fq + e < N) ? acc[i][jj][e] : -INFINITY;
+      float mx = v[0];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) mx = fmaxf(mx, v[k]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sm = 0.f;
+      if (mx > -INFINITY) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sm += __builtin_amdgcn_exp2f(v[k] - mx);
+      }
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      const int m = m_base + 16 * i + fr;
+      if (fq == 0 && m < M) {
+        const size_t o = ((size_t)z * M + m) * parts + part_idx;
+        pmax[o] = mx; psum[o] = sm;
+      }
+    }
+  }
+};
+
+struct EpiColSum {
+  static constexpr int kReduce = 2;
+  static constexpr bool kWide = false, kResidual = false;
+  static constexpr int kColVecs = 0;
+  const float* rmax; const float* rinv; const float* roww; float* part; int nblk; int M, N;   // part [z][nblk][N]
+  __device__ __forceinline__ void load_cols(int, float4&, float4&) const {}
+  __device__ __forceinline__ float4 load_res(int, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ void flush_peak(float) const {}
+  __device__ __forceinline__ void finish4n(int, int, int, f32x4, float4, float4, float4, float&) const {}
+  __device__ __forceinline__ void store4n(int, int, int, f32x4) const {}
+  __device__ __forceinline__ void reduce_tile(int z, int m_base, int n_base, int block, const f32x4 (&acc)[8][4],
+                                              int fr, int fq) const {
+    float mrow[8], srow[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m_base + 16 * i + fr;
+      const bool ok = m < M;
+      const size_t o = (size_t)z * M + (ok ? m : 0);
+      mrow[i] = ok ? rmax[o] : INFINITY;          // rows past M: exp2(S - inf) = 0, never inf * 0
+      float sc = rinv[o];
+      if (roww) sc *= roww[o];
+      srow[i] = ok ? sc : 0.f;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      float c[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a += __builtin_amdgcn_exp2f(acc[i][jj][e] - mrow[i]) * srow[i];   // rows ascending: fixed order
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) a += __shfl_xor(a, o, 64);      // the 16 rows (lanes fr) of a fragment
+        c[e] = a;
+      }
+      const int n0 = n_base + 16 * jj + 4 * fq;
+      if (fr == 0) {
+        float* dst = part + ((size_t)z * nblk + block) * N + n0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n0 + e < N) dst[e] = c[e];
+      }
+    }
   }
 };
 
@@ -425,6 +524,10 @@ int launch(const GemmShape& g, const Epi& epi, int batch, hipStream_t st, bool r
     return COGAIM_EINVAL;
   const int tm2 = (g.M + BM2 - 1) / BM2, tn2 = (g.N + BN2 - 1) / BN2;
   const long long tiles2 = (long long)tm2 * tn2;
+  if constexpr (Epi::kReduce != 0) {       // in-register reductions exist in the persistent kernel only
+    if (tiles2 * batch >= (1 << 30)) return COGAIM_EINVAL;
+    return launch_persistent<T, Epi, SWAP>(g, epi, batch, st, nullptr, 0, true, 0);
+  }
   if (g_gemm_algo >= 1 && tiles2 * batch >= 128 && tiles2 * batch < (1 << 30))
     return launch_persistent<T, Epi, SWAP>(g, epi, batch, st, workspace, workspace_bytes, g_gemm_algo == 2,
                                            g_gemm_diag);
@@ -489,6 +592,33 @@ int cogaim_gemm_batched_f32(const void* A, const void* W, float* out, int M, int
   EpiStoreF32 e{out, ldc, strideC, M, N};
   return DISPATCH_T(dtype, (launch<__bf16, EpiStoreF32, true>(g, e, batch, (hipStream_t)stream, true)),
                     (launch<_Float16, EpiStoreF32, true>(g, e, batch, (hipStream_t)stream, true)));
+}
+
+// ---- focal scores without a score matrix in memory (src/model.py:197-204, 234 for large grids) -----------------
+int cogaim_focal_rowstats_parts(int N) { return ((N + BN2 - 1) / BN2) * 4; }
+int cogaim_focal_scores_colsum_blocks(int N) { return ((N + BM2 - 1) / BM2) * 2; }
+
+// S[z] = Y[z] X[z]^T is formed tile by tile and only its row statistics leave the chip:
+// pmax / psum [batch][N][cogaim_focal_rowstats_parts(N)] = max and sum of exp2(S - max) over each 64-column strip.
+int cogaim_focal_scores_rowstats(const void* Y, const void* X, float* pmax, float* psum, int N, int D, int ld,
+                                 long long stride, int batch, int dtype, void* stream) {
+  GemmShape g{Y, X, N, N, D, ld, ld, stride, stride};
+  if (!pmax || !psum || batch <= 0 || (stride & 7)) return COGAIM_EINVAL;
+  EpiRowStats e{pmax, psum, cogaim_focal_rowstats_parts(N), N, N};
+  return DISPATCH_T(dtype, (launch<__bf16, EpiRowStats, true>(g, e, batch, (hipStream_t)stream, true)),
+                    (launch<_Float16, EpiRowStats, true>(g, e, batch, (hipStream_t)stream, true)));
+}
+
+// The tiles again, now normalised with the finished row statistics and summed over rows:
+// part[z][blk][c] = sum over the 128 rows n of block blk of roww[z][n] exp2(S[n][c] - rmax[z][n]) rinv[z][n]
+// (roww NULL = 1), part [batch][cogaim_focal_scores_colsum_blocks(N)][N].
+int cogaim_focal_scores_colsum(const void* Y, const void* X, const float* rmax, const float* rinv, const float* roww,
+                               float* part, int N, int D, int ld, long long stride, int batch, int dtype, void* stream) {
+  GemmShape g{Y, X, N, N, D, ld, ld, stride, stride};
+  if (!rmax || !rinv || !part || batch <= 0 || (stride & 7)) return COGAIM_EINVAL;
+  EpiColSum e{rmax, rinv, roww, part, cogaim_focal_scores_colsum_blocks(N), N, N};
+  return DISPATCH_T(dtype, (launch<__bf16, EpiColSum, true>(g, e, batch, (hipStream_t)stream, true)),
+                    (launch<_Float16, EpiColSum, true>(g, e, batch, (hipStream_t)stream, true)));
 }
 
 // Patch-embedding GEMM: rows are im2col'ed patches (B*P rows, K padded to a multiple of 64);

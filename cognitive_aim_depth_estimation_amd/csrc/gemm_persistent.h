@@ -250,7 +250,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
       const int m_base = tm * BM2 + wr * 128, n_base = tn * BN2 + wc * 64;
       float peak = 0.f;           // fp16 range guard of the 16-bit epilogues (see track_peak)
       // all loads of the tile first, then the stores (see the note above the epilogues in gemm.hip)
-      if constexpr (WIDE) {
+      if constexpr (Epi::kReduce == 1) {
+        epi.reduce_tile(z, m_base, n_base, tn * 4 + wc, acc, fr, fq);
+      } else if constexpr (Epi::kReduce == 2) {
+        epi.reduce_tile(z, m_base, n_base, tm * 2 + wr, acc, fr, fq);
+      } else if constexpr (WIDE) {
         float4 cb[4], cl;
 #pragma unroll
         for (int q = 0; q < 4; ++q) epi.load_cols(n_base + 8 * fq + 4 * (q & 1) + 32 * (q >> 1), cb[q], cl);
@@ -430,7 +434,7 @@ int launch_persistent(const GemmShape& g, const Epi& epi, int batch, hipStream_t
   const int band = (g_gemm_band >= 0) ? g_gemm_band : ((tn2 % 4 == 0 && tn2 >= 8) ? 8 : 1);
   PersistSched sc{tm2, tn2, band, tiles_per_z, (tiles / lanes) * lanes, 0, 0, 1, 0, (float*)workspace, 0};
   const int rem = tiles - sc.n_full;
-  if (rem > 0 && persistent && g_gemm_quads && rem * 4 <= lanes && lanes == CUS && nk <= 16) {
+  if (rem > 0 && persistent && g_gemm_quads && rem * 4 <= lanes && lanes == CUS && nk <= 16 && Epi::kReduce == 0) {
     // a short last round of a short K: quadrant items on 4 x rem workgroups (every workgroup has whole tiles before
     // it).  Same-box A/B at M = 43840: K = 768 shapes 3-4 us faster than K-split + fix-up launch (fc1 226 -> 222,
     // QKV 150 -> 146), K = 3072 16 us slower (a quadrant item walks all 48 K-tiles at its latency-bound pace)

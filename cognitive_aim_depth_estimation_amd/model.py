@@ -249,6 +249,8 @@ class CognitiveAimModel(nn.Module):
         # the draws it takes from torch's CPU generator (:609, :744), which fix where the guided path's per-call
         # nn.Linear(768, 64) (:1417-1422) falls in the random stream.  Its score still reaches no output.
         self.faithful_curiosity = bool(config.get("faithful_curiosity", False))
+        # largest patch grid whose fp32 focal scores are kept in memory (see _workspace); tests lower it
+        self.scores_in_memory_max_patches = int(config.get("focal_scores_in_memory_max_patches", 1536))
         # replay the per-shape launch sequence as one HIP graph after its first (eager) run
         self.use_graph = bool(config.get("use_hip_graph", os.environ.get("COGAIM_GRAPH", "1") != "0"))
 
@@ -397,12 +399,20 @@ class CognitiveAimModel(nn.Module):
         M = B * T
         Tp = (T + 63) // 64 * 64
         ldS = (N + 127) // 128 * 128
-        nblk = (N + call("cogaim_focal_colsum_rows") - 1) // call("cogaim_focal_colsum_rows")
+        # Grids up to 1536 patches keep the fp32 focal scores of one iteration in memory (every score is then read
+        # once for all row statistics); larger grids (120 MB of scores per image at 1036 pixels) never store them:
+        # the score tiles are formed three times and reduced in registers (_focal).
+        tiled = N > self.scores_in_memory_max_patches
+        nblk = call("cogaim_focal_scores_colsum_blocks", N) if tiled else \
+            (N + call("cogaim_focal_colsum_rows") - 1) // call("cogaim_focal_colsum_rows")
+        parts = call("cogaim_focal_rowstats_parts", N) if tiled else 0
         f32 = dict(device=dev, dtype=torch.float32)
         h16 = dict(device=dev, dtype=tdt)
-        big_bytes = max(M * 4 * D * 2, B * N * self._packed["pe_kp"] * 2, B * N * ldS * 4 if self.use_focal else 0)
+        big_bytes = max(M * 4 * D * 2, B * N * self._packed["pe_kp"] * 2,
+                        B * N * ldS * 4 if (self.use_focal and not tiled) else 0)
         ws = {
-            "N": N, "T": T, "M": M, "Tp": Tp, "ldS": ldS, "nblk": nblk,
+            "N": N, "T": T, "M": M, "Tp": Tp, "ldS": ldS, "nblk": nblk, "tiled": tiled, "parts": parts,
+            "pstat": torch.empty(2, B * N * parts, **f32) if (tiled and self.use_focal) else None,
             "x": torch.empty(M, D, **f32), "tokens": torch.empty(M, D, **f32),
             "h": torch.empty(M, D, **h16), "qk": torch.empty(M, 3 * D, **h16),     # query | key | value
             "ctx": torch.empty(M, D, **h16),
@@ -486,13 +496,25 @@ class CognitiveAimModel(nn.Module):
             # Y = X~ M^T + v into the first D columns' worth of the qk buffer, then S[b] = Y[b] X~[b]^T (log2 domain)
             call("cogaim_gemm_bias_half", h, ptr(f["wm"]), ptr(f["bv"]), qk, B * N, D, D, D, D, D, 0, 1.0, dt,
                  ws["gemm_ws"].data_ptr(), ws["gemm_ws"].numel(), ws["flags"].data_ptr() + 4 * _FLAG_RANGE, st)
-            call("cogaim_gemm_batched_f32", qk, h, S, N, N, D, D, D, ldS, N * D, N * D, N * ldS, B, dt, st)
-            call("cogaim_focal_softmax_stats_colsum", S, ldS, N * ldS, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["part"]), B, N, st)
+            if ws["tiled"]:
+                # no score matrix in memory: S tiles are formed three times and reduced in registers
+                pm, pl = ws["pstat"][0].data_ptr(), ws["pstat"][1].data_ptr()
+                call("cogaim_focal_scores_rowstats", qk, h, pm, pl, N, D, D, N * D, B, dt, st)
+                call("cogaim_focal_rowstats_combine", pm, pl, ws["parts"], ptr(ws["rmax"]), ptr(ws["rinv"]), B, N, st)
+                call("cogaim_focal_scores_colsum", qk, h, ptr(ws["rmax"]), ptr(ws["rinv"]), None, ptr(ws["part"]), N, D, D,
+                     N * D, B, dt, st)
+            else:
+                call("cogaim_gemm_batched_f32", qk, h, S, N, N, D, D, D, ldS, N * D, N * D, N * ldS, B, dt, st)
+                call("cogaim_focal_softmax_stats_colsum", S, ldS, N * ldS, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["part"]), B, N, st)
             call("cogaim_focal_attention_vector", ptr(ws["part"]), ptr(cb), ptr(ws["attn"]), ptr(ws["stats"]),
-                 s_in, s_out, self.focus_strength, B, N, st)
+                 s_in, s_out, self.focus_strength, B, N, ws["nblk"], st)
             call("cogaim_focal_var_flag", ptr(ws["stats"]), B, N, ptr(ws["flags"]), i, st)
-            call("cogaim_focal_weighted_colsum", S, ldS, N * ldS, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["attn"]), ptr(ws["part"]), B, N, st)
-            call("cogaim_focal_reduce_u", ptr(ws["part"]), ptr(ws["u"]), ptr(ws["usum"]), B, N, st)
+            if ws["tiled"]:
+                call("cogaim_focal_scores_colsum", qk, h, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["attn"]), ptr(ws["part"]),
+                     N, D, D, N * D, B, dt, st)
+            else:
+                call("cogaim_focal_weighted_colsum", S, ldS, N * ldS, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["attn"]), ptr(ws["part"]), B, N, st)
+            call("cogaim_focal_reduce_u", ptr(ws["part"]), ptr(ws["u"]), ptr(ws["usum"]), B, N, ws["nblk"], st)
             call("cogaim_weighted_tokens", tok, tstride, s_in, ptr(pe), ptr(ws["u"]), ptr(ws["wt"]), ptr(ws["wtpart"]), B, N, D, st)
             self._linear(ptr(ws["wt"]), D, pfx + "value_proj", ptr(ws["w"]), D, B, bias_scale=ws["usum"])
             self._linear(ptr(ws["w"]), D, pfx + "projection.0", ptr(ws["t256"]), 256, B, act=1)

@@ -116,10 +116,28 @@ int cogaim_focal_colsum_rows(void);
 int cogaim_focal_softmax_stats_colsum(const float* S, int ldS, long long strideS, float* rmax, float* rinv, float* part,
                                       int B, int N, void* stream);
 
-/* :239-282 centre bias, L1 normalise, clamp, renormalise -> a[B,N]; also :426 next-iteration token scale. */
+/* :239-282 centre bias, L1 normalise, clamp, renormalise -> a[B,N]; also :426 next-iteration token scale.
+ * part [B, nblk, N] column-sum partials; nblk <= 0 = ceil(N / cogaim_focal_colsum_rows()). */
 int cogaim_focal_attention_vector(const float* part, const float* center_bias, float* a, double* stats,
                                   const float* scale_in, float* scale_out, float focus_strength, int B, int N,
+                                  int nblk, void* stream);
+
+/* The same :197-204, :234 for large grids, with no score matrix in memory (N x N fp32 is 120 MB per image at
+ * 1036 pixels): S = Y X^T is formed tile by tile three times and reduced in registers --
+ *   rowstats: max and sum of exp2(S - max) per row and 64-column strip -> pmax / psum [batch][N][parts],
+ *             parts = cogaim_focal_rowstats_parts(N); combine: -> rmax / rinv [B*N];
+ *   colsum:   part[z][blk][c] = sum over the 128 rows n of block blk of roww[n] exp2(S[n][c] - rmax[n]) rinv[n]
+ *             (roww NULL = 1), part [batch][cogaim_focal_scores_colsum_blocks(N)][N] -- once with roww NULL for the
+ *             column mean of :234, once with roww = a for (a^T P) of :204/:308.
+ * Y, X 16-bit [batch][N, D] with leading dimension ld and `stride` elements between images. */
+int cogaim_focal_rowstats_parts(int N);
+int cogaim_focal_scores_colsum_blocks(int N);
+int cogaim_focal_scores_rowstats(const void* Y, const void* X, float* pmax, float* psum, int N, int D, int ld,
+                                 long long stride, int batch, int dtype, void* stream);
+int cogaim_focal_rowstats_combine(const float* pmax, const float* psum, int parts, float* rmax, float* rinv, int B, int N,
                                   void* stream);
+int cogaim_focal_scores_colsum(const void* Y, const void* X, const float* rmax, const float* rinv, const float* roww,
+                               float* part, int N, int D, int ld, long long stride, int batch, int dtype, void* stream);
 
 /* :242 `patch_attention.var() < 1e-6` over the whole batch, evaluated on device into flags[slot]. */
 int cogaim_focal_var_flag(const double* stats, int B, int N, int* flags, int slot, void* stream);
@@ -127,7 +145,7 @@ int cogaim_focal_var_flag(const double* stats, int B, int N, int* flags, int slo
 /* :204,:308  sum_n a_n (P V)_n = (a^T P) V:  part[b][blk][c] = sum_{n in blk} roww[b][n] P[b][n][c]. */
 int cogaim_focal_weighted_colsum(const float* S, int ldS, long long strideS, const float* rmax, const float* rinv,
                                  const float* roww, float* part, int B, int N, void* stream);
-int cogaim_focal_reduce_u(const float* part, float* u, float* usum, int B, int N, void* stream);
+int cogaim_focal_reduce_u(const float* part, float* u, float* usum, int B, int N, int nblk, void* stream);
 
 /* out[b][:] = sum_n w[b][n] * (tok[b][n][:] * scale[b][n] + pe[n][:]);  scale/pe NULL = 1/0.
  * Used for (a^T P) Xt above and for the guided token sum of src/model.py:1412-1414.

@@ -128,11 +128,16 @@ def test_full_size_vs_oracle(dtype):
     assert gerr <= 1e-2
 
 
-def test_focal_stream_vs_oracle():
-    """Iterative focal stream alone (fp32 tokens in, features + attention out), N = 1369 and a ragged N."""
+@pytest.mark.parametrize("tiled", [False, True])
+def test_focal_stream_vs_oracle(tiled):
+    """Iterative focal stream alone (fp32 tokens in, features + attention out), N = 1369 and a ragged N; with the
+    scores kept in memory, and with the score tiles reduced in registers (the form large grids take), which also
+    runs the 74 x 74 grid of 1036-pixel inputs at B = 2."""
     model, sd = synth_model_and_sd(1, 4, iters=3, seed=3, dtype="fp16")
+    if tiled:
+        model.scores_in_memory_max_patches = 0
     model._pack()
-    for B, g in ((2, 37), (3, 5)):
+    for B, g in ((2, 37), (3, 5)) + (((2, 74),) if tiled else ()):
         N, D = g * g, 768
         ws = model._workspace(B, g, g)
         torch.manual_seed(g)
@@ -144,7 +149,9 @@ def test_focal_stream_vs_oracle():
         torch.cuda.synchronize()
         f_ref, a_ref = O.iterative_focal_stream(sd, tokens[:, 1:], 3, 1.5)
         ea, ef = rel_err(ws["attn"], a_ref), float((ws["cat"][:, 64:128].cpu() - f_ref).abs().max() / f_ref.abs().max())
-        report(test="focal_stream", N=N, attn=ea, feat=ef)
+        report(test="focal_stream", N=N, tiled=tiled, attn=ea, feat=ef)
+        no_scores = max(ws["M"] * 4 * D * 2, B * N * 640 * 2)        # fc1 output / im2col columns only
+        assert ws["tiled"] == tiled and (ws["big"].numel() == no_scores) == (tiled or B * N * ws["ldS"] * 4 <= no_scores)
         assert ea <= 2e-2 and ef <= 5e-3, (ea, ef)
         assert int(ws["flags"].sum()) == 0
 
