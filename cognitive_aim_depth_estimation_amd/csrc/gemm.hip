@@ -241,7 +241,7 @@ template <class T> struct EpiBiasGeluHalf {
 
 struct EpiResidualF32 {                            // x += (acc + bias) * layerscale   (in place)
   static constexpr int kReduce = 0;   // 1 / 2: the tile is reduced in registers instead of stored (EpiRowStats / EpiColSum)
-  static constexpr bool kWide = false, kResidual = true;
+    static constexpr bool kWide = false, kResidual = true;
   static constexpr int kColVecs = 2;   // per-column vectors load_cols fills: 0 none, 1 bias, 2 bias and scale
   float* x; const float* bias; const float* ls; int ldc; int M, N;
   __device__ __forceinline__ void load_cols(int n0, float4& b, float4& l) const {

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
   const T* sAe[2]; const T* sAl[2]; const T* sWe[2]; const T* sWl[2];
   int d_item = 0, d_kt = 0, d_kt1 = 0;                  // DMA cursor
   bool d_valid = true;
-  auto dma_set_tile = [&](int tile) {
+  auto dma_set_tile = [&](int tile, int lane) {        // `lane`: see the quadrant items for why it is a parameter
     const int z = tile / sc.tiles_per_z, lt = tile - z * sc.tiles_per_z;
     int tm, tn; tile_coords(sc, lt, tm, tn);
     const T* A = A0 + z * g.strideA;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
   auto dma_set_item = [&](int j) {
     const Item it = item_at(j);
     d_kt = it.kt0; d_kt1 = it.kt1;
-    dma_set_tile(it.tile);
+    dma_set_tile(it.tile, lane);
   };
   auto dma_advance = [&]() {        // after the 4 phases of one K-tile have issued its pieces
     if (++d_kt >= d_kt1) {
@@ -335,7 +335,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
     const int qt = ((bid >> 5) << 3) + (bid & 7), q = (bid >> 3) & 3;
     if (qt < sc.n_split) {
       const int tile = sc.n_full + qt;
-      dma_set_tile(tile);
+      // The lane id goes through an empty asm first: otherwise the compiler computes this block's per-lane source
+      // addresses ahead of the main loop (they depend on nothing it produces) and keeps them in registers across it,
+      // which costs the main loop 4-7 spilled registers.
+      int lane_q = lane;
+      asm volatile("" : "+v"(lane_q));
+      dma_set_tile(tile, lane_q);
       const int z = tile / sc.tiles_per_z, lt = tile - z * sc.tiles_per_z;
       int tm, tn; tile_coords(sc, lt, tm, tn);
       const int m_base = tm * BM2 + wr * 128, n_base = tn * BN2 + wc * 64;

@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cognitive_aim_depth_estimation_amd._lib import call, ptr, stream_ptr  # noqa: E402
 
-M = 43840
+M = int(os.environ.get("M", "43840"))
 dt, tdt = (0, torch.bfloat16) if os.environ.get("BF16") else (1, torch.float16)
 dev = "cuda"
 torch.manual_seed(0)
