@@ -50,7 +50,7 @@ _FLAG_CAMERA = 63       # camera_idx outside the embedding table
 # --------------------------------------------------------------------------
 def state_spec(hidden: int, layers: int, patch: int, native_grid: int, num_iterations: int,
                num_cameras: int, use_ambient: bool, use_focal: bool, use_exif: bool,
-               curiosity_guided: bool) -> "OrderedDict[str, Tuple[tuple, torch.dtype]]":
+               curiosity_guided: bool, iterative: bool = True) -> "OrderedDict[str, Tuple[tuple, torch.dtype]]":
     """Key -> (shape, dtype) in the reference's registration order."""
     D, f32 = hidden, torch.float32
     s: "OrderedDict[str, Tuple[tuple, torch.dtype]]" = OrderedDict()
@@ -84,7 +84,17 @@ def state_spec(hidden: int, layers: int, patch: int, native_grid: int, num_itera
         lin("ambient_stream.mlp.0", 256, D)
         lin("ambient_stream.mlp.3", 128, 256)
         lin("ambient_stream.mlp.5", 64, 128)
-    if use_focal:
+    if use_focal and not iterative:
+        # a bare FocalStream (src/model.py:869-870); its constructor default keeps the curiosity modulator (:58, :73-79)
+        p = "focal_stream."
+        s[p + "adaptive_weight"] = ((), f32)
+        for n in ("query_proj", "key_proj", "value_proj"):
+            lin(p + n, D, D)
+        lin(p + "curiosity_modulator.0", 32, 1)
+        lin(p + "curiosity_modulator.2", 8, 32)
+        lin(p + "projection.0", 256, D)
+        lin(p + "projection.3", 64, 256)
+    elif use_focal:
         s["focal_stream.initial_focus"] = ((1, D), f32)
         for i in range(num_iterations):
             p = f"focal_stream.focal_streams.{i}."
@@ -166,6 +176,9 @@ def _init_tensor(key: str, shape, dtype, gen: torch.Generator) -> torch.Tensor:
             it = int(key.split(".focal_streams.")[1].split(".")[0])
             gain = (1.0 if "value_proj" in key else 1.2) * (1.0 + 0.1 * it)
             return torch.randn(shape, generator=gen) * (gain * math.sqrt(2.0 / (i + o)))
+        if key in ("focal_stream.query_proj.weight", "focal_stream.key_proj.weight", "focal_stream.value_proj.weight"):
+            gain = 1.0 if "value_proj" in key else 2.0                     # src/model.py:116-118
+            return torch.randn(shape, generator=gen) * (gain * math.sqrt(2.0 / (i + o)))
         if key.startswith("focal_stream.") or key == "decision_head.0.weight":
             gain = 1.0 if key == "decision_head.0.weight" else 0.8
             bound = gain * math.sqrt(6.0 / (i + o))
@@ -216,9 +229,9 @@ class CognitiveAimModel(nn.Module):
                 raise ValueError(f"focal_config.num_iterations must be in 1..{_MAX_ITERATIONS}")
             if config.get("focal_hidden_dim", 256) != 256:
                 raise NotImplementedError("focal_hidden_dim != 256")
-        elif "focal_stream" in modules:
-            raise NotImplementedError("the non-iterative 'focal_stream' module is not built; every shipped "
-                                      "config selects 'iterative_focal_stream'")
+        elif "focal_stream" in modules:                       # one bare FocalStream (src/model.py:869-873)
+            self.use_focal, self.use_iterative = True, False
+            self.num_iterations, self.focus_strength = 1, 0.0
         else:
             self.use_focal, self.use_iterative = False, False
             self.num_iterations, self.focus_strength = 0, 0.0
@@ -256,7 +269,7 @@ class CognitiveAimModel(nn.Module):
 
         spec = state_spec(self.feature_dim, self.num_layers, self.patch_size, self.native_grid,
                           self.num_iterations, num_cameras, self.use_ambient, self.use_focal,
-                          self.use_exif, self.curiosity_guided)
+                          self.use_exif, self.curiosity_guided, self.use_iterative or not self.use_focal)
         gen = torch.Generator().manual_seed(int(config.get("init_seed", 0)))
         for key, (shape, dtype) in spec.items():
             node = self
@@ -343,8 +356,7 @@ class CognitiveAimModel(nn.Module):
         pk["gf"] = sd["backbone.layernorm.weight"].float().contiguous()
         pk["bf"] = sd["backbone.layernorm.bias"].float().contiguous()
         focal = []
-        for i in range(self.num_iterations):
-            p = f"focal_stream.focal_streams.{i}."
+        for p in self._focal_prefixes():
             # Row softmax of Q K^T ignores terms that are constant along a row, so
             #   (X Wq^T + bq)(X Wk^T + bk)^T  ~  (X (Wq^T Wk) + bq^T Wk) X^T :
             # ONE 768-wide projection Y = X M^T + v with M = Wk^T Wq, v = bq Wk (softmax scale and log2 e folded
@@ -363,6 +375,14 @@ class CognitiveAimModel(nn.Module):
             ws.pop("graphs", None)
         self._tab.clear()
         return pk
+
+    def _focal_prefixes(self):
+        """state_dict prefix of every FocalStream in evaluation order."""
+        if not self.use_focal:
+            return []
+        if not self.use_iterative:
+            return ["focal_stream."]
+        return [f"focal_stream.focal_streams.{i}." for i in range(self.num_iterations)]
 
     def _table(self, kind: str, *key) -> torch.Tensor:
         k = (kind,) + key
@@ -489,7 +509,7 @@ class CognitiveAimModel(nn.Module):
         I = self.num_iterations
         for i in range(I):
             f = pk["focal"][i]
-            pfx = f"focal_stream.focal_streams.{i}."
+            pfx = self._focal_prefixes()[i]
             s_in = None if i == 0 else ws["scale"][i % 2].data_ptr()
             s_out = None if i == I - 1 else ws["scale"][(i + 1) % 2].data_ptr()
             call("cogaim_focal_prep", tok, tstride, s_in, ptr(pe), h, B, N, D, dt, st)
@@ -519,11 +539,15 @@ class CognitiveAimModel(nn.Module):
             self._linear(ptr(ws["wt"]), D, pfx + "value_proj", ptr(ws["w"]), D, B, bias_scale=ws["usum"])
             self._linear(ptr(ws["w"]), D, pfx + "projection.0", ptr(ws["t256"]), 256, B, act=1)
             self._linear(ptr(ws["t256"]), 256, pfx + "projection.3", ws["feats"].data_ptr() + 64 * i * 4, 64 * I, B)
-        self._linear(ptr(ws["feats"]), 64 * I, "focal_stream.fusion.0", ptr(ws["t128"]), 128, B, act=1)
+        if self.use_iterative:
+            self._linear(ptr(ws["feats"]), 64 * I, "focal_stream.fusion.0", ptr(ws["t128"]), 128, B, act=1)
         return ws["attn"]
 
     def _focal_fused_into(self, ws, B, col):
-        self._linear(ptr(ws["t128"]), 128, "focal_stream.fusion.2", ws["cat"].data_ptr() + col * 4, 192, B)
+        if self.use_iterative:      # fusion MLP over the concatenated per-iteration features (src/model.py:430)
+            self._linear(ptr(ws["t128"]), 128, "focal_stream.fusion.2", ws["cat"].data_ptr() + col * 4, 192, B)
+        else:                       # a bare FocalStream returns its projected features as they are (:311)
+            ws["cat"][:, col:col + 64].copy_(ws["feats"])
 
     def _check_fallback_flags(self, ws):
         """The reference switches to other attention summaries when the whole-batch variance
@@ -849,6 +873,8 @@ class CognitiveAimModel(nn.Module):
         gkey = ("mask", attention_guidance.lower(), math.isqrt(N)) if isinstance(attention_guidance, str) else None
         gdev = self._table(*gkey) if gkey else g.to(self._packed["device"]).contiguous()
         cdraw = self._curiosity_draw(B) if self.faithful_curiosity else None     # :1185, before the Linear of :1420
+        if not self.use_iterative:
+            temp_projection = (ws["pw"], ws["pb"])            # unused: the stream's own projection is applied
         if temp_projection is None:
             lin = nn.Linear(self.feature_dim, 64)
             temp_projection = (lin.weight.detach(), lin.bias.detach())
@@ -861,7 +887,11 @@ class CognitiveAimModel(nn.Module):
             call("cogaim_guided_attention", ptr(ws["attn"]), ptr(gdev), ptr(ws["guided"]), B, N, 0.7, 0.05, st)
             call("cogaim_weighted_tokens", ws["tokens"].data_ptr() + D * 4, T * D, None, None, ptr(ws["guided"]),
                  ptr(ws["wt"]), ptr(ws["wtpart"]), B, N, D, st)
-            self._linear(ptr(ws["wt"]), D, None, ws["cat"].data_ptr() + col * 4, 192, B, W=pw, bias=pb)
+            if self.use_iterative:
+                self._linear(ptr(ws["wt"]), D, None, ws["cat"].data_ptr() + col * 4, 192, B, W=pw, bias=pb)
+            else:       # a bare FocalStream has its own projection (:1417-1418): no random Linear, deterministic depth
+                self._linear(ptr(ws["wt"]), D, "focal_stream.projection.0", ptr(ws["t256"]), 256, B, act=1)
+                self._linear(ptr(ws["t256"]), 256, "focal_stream.projection.3", ws["cat"].data_ptr() + col * 4, 192, B)
 
         ncols = self._features(images, exif_data, ws, B, focal_override=guided_focal,
                                graph_key=("guided", gdev.data_ptr()) if gkey else None)
@@ -921,14 +951,17 @@ class CognitiveAimModel(nn.Module):
         for k in range(K):                 # the random stream of K single calls: curiosity draws (:1185), then the Linear
             if self.faithful_curiosity:
                 cdraws.append(self._curiosity_draw(B))
-            if given[k] is None:
+            if not self.use_iterative:
+                pairs.append(None)                          # the stream's own projection: nothing drawn
+            elif given[k] is None:
                 lin = nn.Linear(self.feature_dim, 64)
                 pairs.append((lin.weight.detach(), lin.bias.detach()))
             else:
                 pairs.append(given[k])
-        for k, (w, b) in enumerate(pairs):
-            sw["pw"][k].copy_(w.reshape(64, D), non_blocking=True)       # static buffers: the captured sequence
-            sw["pb"][k].copy_(b.reshape(64), non_blocking=True)          # reads these addresses
+        for k, pair in enumerate(pairs):
+            if pair is not None:
+                sw["pw"][k].copy_(pair[0].reshape(64, D), non_blocking=True)     # static buffers: the captured sequence
+                sw["pb"][k].copy_(pair[1].reshape(64), non_blocking=True)        # reads these addresses
         col_focal = []
 
         def tail():
@@ -939,8 +972,12 @@ class CognitiveAimModel(nn.Module):
                  ptr(sw["wtpart"]), B, N, D, K, st)
             sw["cat"].copy_(ws["cat"].unsqueeze(0).expand(K, B, 192))      # ambient / EXIF columns of every image
             for k in range(K):
-                self._linear(sw["wt"].data_ptr() + k * B * D * 4, D, None, sw["cat"].data_ptr() + (k * B * 192 + col) * 4,
-                             192, B, W=sw["pw"][k], bias=sw["pb"][k])
+                wt_k, cat_k = sw["wt"].data_ptr() + k * B * D * 4, sw["cat"].data_ptr() + (k * B * 192 + col) * 4
+                if self.use_iterative:
+                    self._linear(wt_k, D, None, cat_k, 192, B, W=sw["pw"][k], bias=sw["pb"][k])
+                else:
+                    self._linear(wt_k, D, "focal_stream.projection.0", ptr(ws["t256"]), 256, B, act=1)
+                    self._linear(ptr(ws["t256"]), 256, "focal_stream.projection.3", cat_k, 192, B)
             self._linear(ptr(sw["cat"]), 192, "fusion.0", ptr(sw["fused"]), 192, K * B, act=1)
             out = sw["out"]
             call("cogaim_heads", ptr(sw["fused"]), 192, ptr(f["decision_head.0.weight"]), ptr(f["decision_head.0.bias"]),

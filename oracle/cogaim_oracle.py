@@ -321,8 +321,9 @@ def model_config_from_sd(sd: SD) -> dict:
     n_iter = 0
     while f"focal_stream.focal_streams.{n_iter}.query_proj.weight" in sd:
         n_iter += 1
-    return {"use_ambient": "ambient_stream.mlp.0.weight" in sd,
-            "use_focal": n_iter > 0, "num_iterations": n_iter,
+    single = "focal_stream.query_proj.weight" in sd            # a bare FocalStream (model.py:869-870)
+    return {"use_ambient": "ambient_stream.mlp.0.weight" in sd, "single_focal": single,
+            "use_focal": n_iter > 0 or single, "num_iterations": n_iter,
             "use_exif": "exif_prior.camera_embedding.weight" in sd}
 
 
@@ -338,7 +339,10 @@ def forward(sd: SD, images: Tensor, exif: Optional[Dict[str, Tensor]] = None,
     feats, attn = [], None
     if cfg["use_ambient"]:
         feats.append(ambient_stream(sd, cls))
-    if cfg["use_focal"]:
+    if cfg["single_focal"]:
+        f, attn = focal_stream(sd, "focal_stream.", patches)
+        feats.append(f)
+    elif cfg["use_focal"]:
         f, attn = iterative_focal_stream(sd, patches, cfg["num_iterations"], focus_strength)
         feats.append(f)
     if cfg["use_exif"] and exif is not None:
@@ -367,16 +371,22 @@ def forward_with_guidance(sd: SD, images: Tensor, exif: Optional[Dict[str, Tenso
     cfg = model_config_from_sd(sd)
     lhs = dinov2_forward(sd, images, n_heads=n_heads)
     cls, patches = lhs[:, 0], lhs[:, 1:]
-    base_f, base_a = iterative_focal_stream(sd, patches, cfg["num_iterations"], focus_strength)
+    if cfg["single_focal"]:
+        base_f, base_a = focal_stream(sd, "focal_stream.", patches)
+    else:
+        base_f, base_a = iterative_focal_stream(sd, patches, cfg["num_iterations"], focus_strength)
     if guidance is None:
         focal_f, attn = base_f, base_a
     else:
         g = resolve_guidance(guidance, patches.size(1))
         attn = guided_attention(base_a, g)
         weighted = torch.sum(patches * attn.unsqueeze(-1), dim=1)   # :1412-1414
-        if temp_projection is None:
+        if cfg["single_focal"]:                                     # :1417-1418: the stream's own projection
+            focal_f = _lin(sd, "focal_stream.projection.3", F.relu(_lin(sd, "focal_stream.projection.0", weighted)))
+        elif temp_projection is None:
             return None, None, attn
-        focal_f = F.linear(weighted, temp_projection[0], temp_projection[1])
+        else:
+            focal_f = F.linear(weighted, temp_projection[0], temp_projection[1])
     feats = []
     if cfg["use_ambient"]:
         feats.append(ambient_stream(sd, cls))

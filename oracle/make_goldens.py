@@ -307,6 +307,79 @@ def g8_curiosity_state(ref):
     save("g8_curiosity_state", **arrays)
 
 
+def g9_single_patch(ref):
+    """14 x 14 inputs: ONE patch, the only grid on which the degenerate-attention fallbacks of src/model.py:242-257
+    fire naturally (column mean + centre bias is the constant 1.3 for every image, so its whole-batch variance is
+    0 for B >= 2; all three fallbacks then run, the last one drawing noise).  With one patch every branch
+    normalises to the same attention vector [1.0], so outputs do not depend on the branch taken."""
+    from transformers import Dinov2Config, Dinov2Model
+    layers, grid = 2, 4
+    ref.Dinov2Model.from_pretrained = classmethod(
+        lambda cls, name, *a, **k: Dinov2Model(Dinov2Config(image_size=14 * grid, num_hidden_layers=layers)))
+    cfg = {"cognitive_modules": ["ambient_stream", "iterative_focal_stream", "exif_prior_database"],
+           "focal_config": {"num_iterations": 3, "focus_strength": 1.5}}
+    with quiet():
+        model = ref.create_model(cfg, {"num_cameras": 71}).eval()
+    spec = reference_state_spec(layers=layers, native_grid=grid, num_iterations=3, num_cameras=71)
+    model.load_state_dict(synth_state_dict(spec, seed=7), strict=True)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(3, 3, 14, 14, generator=g)
+    exif = {"camera_idx": torch.tensor([0, 5, 70]), "focal_length": torch.tensor([50.0, 24.0, 135.0]),
+            "aperture": torch.tensor([2.8, 8.0, 1.8]), "iso": torch.tensor([100.0, 1600.0, 400.0])}
+    arrays = {"layers": layers, "native_grid": grid, "seed": 7, "x": x.numpy()}
+    for k, v in exif.items():
+        arrays["exif:" + k] = v.numpy()
+    drawn, real = [], torch.randn_like
+
+    def spy(t, *a_, **k_):
+        drawn.append(tuple(t.shape))
+        return real(t, *a_, **k_)
+    torch.randn_like = spy
+    try:
+        with torch.no_grad(), quiet():
+            d, c, a = model(x, exif, return_attention=True)
+            _, _, ga = model.forward_with_guidance(x, exif, "center", return_attention=True)
+    finally:
+        torch.randn_like = real
+    assert drawn.count((3, 1)) >= 3          # the third fallback (:252-257) drew its noise in every FocalStream call
+    arrays["fallback_noise_draws"] = drawn.count((3, 1))
+    arrays["depth"], arrays["conf"], arrays["attn"], arrays["guided"] = d.numpy(), c.numpy(), a.numpy(), ga.numpy()
+    save("g9_single_patch", **arrays)
+
+
+def g10_bare_focal_stream(ref):
+    """cognitive_modules with 'focal_stream' instead of 'iterative_focal_stream' (src/model.py:869-873): one
+    FocalStream, curiosity modulator present (constructor default), its own projection on the guided path
+    (:1417-1418), so guided depth is deterministic in this variant."""
+    from transformers import Dinov2Config, Dinov2Model
+    layers, grid = 2, 4
+    ref.Dinov2Model.from_pretrained = classmethod(
+        lambda cls, name, *a, **k: Dinov2Model(Dinov2Config(image_size=14 * grid, num_hidden_layers=layers)))
+    mods = ["ambient_stream", "focal_stream", "exif_prior_database"]
+    with quiet():
+        model = ref.create_model({"cognitive_modules": mods}, {"num_cameras": 71}).eval()
+    spec = reference_state_spec(layers=layers, native_grid=grid, num_cameras=71, modules=tuple(mods))
+    ref_sd = model.state_dict()
+    assert list(ref_sd.keys()) == list(spec.keys()), (set(ref_sd) ^ set(spec))
+    for k, (shp, dt) in spec.items():
+        assert tuple(ref_sd[k].shape) == tuple(shp) and ref_sd[k].dtype == dt, k
+    model.load_state_dict(synth_state_dict(spec, seed=7), strict=True)
+    g = torch.Generator().manual_seed(55)
+    x = torch.randn(2, 3, 70, 70, generator=g)
+    exif = {"camera_idx": torch.tensor([3, 44]), "focal_length": torch.tensor([35.0, 200.0]),
+            "aperture": torch.tensor([4.0, 11.0]), "iso": torch.tensor([200.0, 3200.0])}
+    arrays = {"layers": layers, "native_grid": grid, "seed": 7, "x": x.numpy()}
+    for k, v in exif.items():
+        arrays["exif:" + k] = v.numpy()
+    with torch.no_grad(), quiet() as log:
+        d, c, a = model(x, exif, return_attention=True)
+        gd, gc, ga = model.forward_with_guidance(x, exif, "bottom-left", return_attention=True)
+    assert "failed" not in log.getvalue(), log.getvalue()
+    for k, v in (("depth", d), ("conf", c), ("attn", a), ("guided_depth", gd), ("guided_conf", gc), ("guided_attn", ga)):
+        arrays[k] = v.numpy()
+    save("g10_bare_focal_stream", **arrays)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
@@ -317,6 +390,8 @@ def main():
     g6_pe_table(ref)
     g7_full_model(ref)
     g8_curiosity_state(ref)
+    g9_single_patch(ref)
+    g10_bare_focal_stream(ref)
 
 
 if __name__ == "__main__":

@@ -58,6 +58,16 @@ def reference_state_spec(hidden: int = 768, layers: int = 12, patch: int = 14,
         lin("ambient_stream.mlp.0", 256, D)
         lin("ambient_stream.mlp.3", 128, 256)
         lin("ambient_stream.mlp.5", 64, 128)
+    if "focal_stream" in modules and "iterative_focal_stream" not in modules:
+        p = "focal_stream."
+        s[p + "adaptive_weight"] = ((), f32)
+        lin(p + "query_proj", D, D)
+        lin(p + "key_proj", D, D)
+        lin(p + "value_proj", D, D)
+        lin(p + "curiosity_modulator.0", 32, 1)
+        lin(p + "curiosity_modulator.2", 8, 32)
+        lin(p + "projection.0", 256, D)
+        lin(p + "projection.3", 64, 256)
     if "iterative_focal_stream" in modules:
         s["focal_stream.initial_focus"] = ((1, D), f32)
         for i in range(num_iterations):
@@ -146,7 +156,7 @@ def synth_tensor(key: str, shape, dtype, seed: int) -> torch.Tensor:
     if leaf == "bias":
         return 0.05 * r
     if leaf == "weight" and len(shape) == 2:
-        if ".query_proj." in key or ".key_proj." in key:
+        if ".query_proj." in key or ".key_proj." in key or key.startswith(("focal_stream.query_proj", "focal_stream.key_proj")):
             return r * (1.2 * math.sqrt(2.0 / (shape[0] + shape[1])))   # src/model.py:379-380
         return r / math.sqrt(shape[1])
     return r

@@ -168,3 +168,32 @@ def test_curiosity_reward_and_ring_buffer_vs_reference():
                 ptr_ = (ptr_ + 1) % 1000
     assert ptr_ == int(z["a:pointer"])
     assert np.allclose(hist, z["a:history"], rtol=1e-5, atol=1e-7), float(np.abs(hist - z["a:history"]).max())
+
+
+def test_single_patch_degenerate_attention_vs_reference():
+    """14 x 14 inputs (one patch): the reference takes all three degenerate-attention fallbacks
+    (src/model.py:242-257, tests/golden/g9_single_patch.npz records the noise draws) and still returns the
+    attention vector [1.0]; the oracle, which restates those branches, agrees."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g9_single_patch.npz"))
+    sd = synth_state_dict(reference_state_spec(layers=int(z["layers"]), native_grid=int(z["native_grid"])), seed=int(z["seed"]))
+    x = torch.from_numpy(z["x"])
+    exif = {k: torch.from_numpy(z["exif:" + k]) for k in ("camera_idx", "focal_length", "aperture", "iso")}
+    d, c, a = O.forward(sd, x, exif, return_attention=True)
+    assert int(z["fallback_noise_draws"]) >= 3
+    assert np.allclose(d.numpy(), z["depth"], rtol=1e-4) and np.allclose(c.numpy(), z["conf"], rtol=1e-4)
+    assert np.array_equal(a.numpy(), z["attn"]) and np.array_equal(z["attn"], np.ones((3, 1), np.float32))
+
+
+def test_bare_focal_stream_variant_vs_reference():
+    """'focal_stream' in cognitive_modules (one FocalStream, its own projection on the guided path):
+    tests/golden/g10_bare_focal_stream.npz from the real reference."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_bare_focal_stream.npz"))
+    mods = ("ambient_stream", "focal_stream", "exif_prior_database")
+    sd = synth_state_dict(reference_state_spec(layers=int(z["layers"]), native_grid=int(z["native_grid"]), modules=mods),
+                          seed=int(z["seed"]))
+    x = torch.from_numpy(z["x"])
+    exif = {k: torch.from_numpy(z["exif:" + k]) for k in ("camera_idx", "focal_length", "aperture", "iso")}
+    d, c, a = O.forward(sd, x, exif, return_attention=True)
+    gd, gc, ga = O.forward_with_guidance(sd, x, exif, "bottom-left")
+    for got, key in ((d, "depth"), (c, "conf"), (a, "attn"), (gd, "guided_depth"), (gc, "guided_conf"), (ga, "guided_attn")):
+        assert np.allclose(got.numpy(), z[key], rtol=1e-4, atol=1e-7), key
