@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=518)
     ap.add_argument("--iters", type=int, default=3, help="focal refinement iterations")
+    ap.add_argument("--backbone", default="base", choices=["base", "large"],
+                    help="backbone_size of the model config (base = ViT-B/14, the headline; large = ViT-L/14)")
     ap.add_argument("--dtype", default=os.environ.get("COGAIM_DTYPE", "bf16"), choices=["fp16", "bf16"],
                     help="headline operand type (BASELINE config 2 is bf16); the other one is timed beside it")
     ap.add_argument("--streams", type=int, default=0,
@@ -201,7 +203,7 @@ def main():
     gathered = torch.empty(world * B, 2, device=dev) if world > 1 else None
 
     def config_for(dtype, **extra):
-        cfg = {"cognitive_modules": MODULES, "compute_dtype": dtype,
+        cfg = {"cognitive_modules": MODULES, "compute_dtype": dtype, "backbone_size": args.backbone,
                "focal_config": {"num_iterations": args.iters, "focus_strength": 1.5}, "init_seed": 0}
         if args.streams > 0:
             cfg["streams"] = args.streams
@@ -245,7 +247,8 @@ def main():
     model, d, c, elapsed = timed_run(args.dtype)
     ms_per_step = 1000.0 * elapsed / args.steps
     value = world * B * args.steps / elapsed
-    fpi = flops_per_image(args.size, args.iters)
+    width, depth_, heads = (1024, 24, 16) if args.backbone == "large" else (768, 12, 12)
+    fpi = flops_per_image(args.size, args.iters, layers=depth_, D=width)
     frac = lambda v: round(v / world * fpi / 1e12 / PEAK_TFLOPS, 4)
     out = {
         "metric": f"images/sec @{args.size}x{args.size} full_cognitive forward (depth+confidence)",
@@ -253,7 +256,7 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic (randn images, demo-default EXIF, seeded random-init weights)",
         "config": {"workload": f"full_cognitive forward, B={B}/GPU, {args.size}x{args.size}, "
-                               f"ViT-B/14 12 layers + {args.iters} focal iterations",
+                               f"ViT-{'L' if args.backbone == 'large' else 'B'}/14 {depth_} layers + {args.iters} focal iterations",
                    "global_batch": world * B, "sharding": f"image-sharded dp{world}" if world > 1 else "single GPU"},
         "algorithmic_gflop_per_image": round(fpi / 1e9, 1),
         "mfma_frac_end_to_end": frac(value),
@@ -316,16 +319,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cogaim_oracle as O
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}      # same seeded weights in every model here
-        nb, nf = min(16, B), min(4, B)        # ~10-20 s of host work in total
+        nb, nf = (min(16, B), min(4, B)) if args.backbone == "base" else (min(6, B), min(2, B))   # ~10-20 s of host work
         xc = images[:nb].cpu()
         ec = {k: v[:nb].cpu() for k, v in exif.items()}
         with torch.no_grad():
-            O.forward(sd, xc[:1], {k: v[:1] for k, v in ec.items()}, focus_strength=1.5)      # warm-up
+            O.forward(sd, xc[:1], {k: v[:1] for k, v in ec.items()}, focus_strength=1.5, n_heads=heads)      # warm-up
             t1 = time.perf_counter()
-            d_ref, c_ref = O.forward(sd, xc, ec)
+            d_ref, c_ref = O.forward(sd, xc, ec, n_heads=heads)
             t_dedup = time.perf_counter() - t1
             t1 = time.perf_counter()
-            O.forward_faithful_schedule(sd, xc[:nf], {k: v[:nf] for k, v in ec.items()})
+            O.forward_faithful_schedule(sd, xc[:nf], {k: v[:nf] for k, v in ec.items()}, n_heads=heads)
             t_faithful = time.perf_counter() - t1
         out["cpu_baseline"] = {
             "value": round(nb / t_dedup, 3), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",

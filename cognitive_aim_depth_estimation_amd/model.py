@@ -208,10 +208,8 @@ class CognitiveAimModel(nn.Module):
         self.config = config
         # -- config resolution, same keys and defaults as reference src/model.py:803-951 --
         self.backbone_size = config.get("backbone_size", "base")
-        self.feature_dim = 1024 if self.backbone_size == "large" else 768
-        if self.feature_dim != 768:
-            raise NotImplementedError("only the dinov2-base geometry (768 wide) is built; the reference's "
-                                      "own heads are hard-wired to 768 as well (src/model.py:918,949)")
+        large = self.backbone_size == "large"          # anything else is dinov2-base (src/model.py:804-812)
+        self.feature_dim = 1024 if large else 768
         self.use_lora = config.get("use_lora", False)
         if self.use_lora:
             raise NotImplementedError("LoRA is unused and broken in the reference (src/model.py:30)")
@@ -241,8 +239,8 @@ class CognitiveAimModel(nn.Module):
         self.target_fusion_dim = 768
         # -- backbone geometry: dinov2-base unless overridden (tests use shallow stacks) --
         bb = config.get("backbone_config", {}) or {}
-        self.num_layers = int(bb.get("num_hidden_layers", 12))
-        self.num_heads = int(bb.get("num_attention_heads", 12))
+        self.num_layers = int(bb.get("num_hidden_layers", 24 if large else 12))
+        self.num_heads = int(bb.get("num_attention_heads", 16 if large else 12))
         self.patch_size = int(bb.get("patch_size", 14))
         self.native_grid = int(bb.get("image_size", 518)) // self.patch_size
         self.layer_norm_eps = float(bb.get("layer_norm_eps", 1e-6))
@@ -261,7 +259,10 @@ class CognitiveAimModel(nn.Module):
         # for the state it leaves behind -- exploration_history / history_pointer, get_exploration_stats() -- and for
         # the draws it takes from torch's CPU generator (:609, :744), which fix where the guided path's per-call
         # nn.Linear(768, 64) (:1417-1422) falls in the random stream.  Its score still reaches no output.
-        self.faithful_curiosity = bool(config.get("faithful_curiosity", False))
+        # The module is 768 wide whatever the backbone (:946-950): on the 1024 columns of backbone_size='large' every
+        # call raises before it draws or stores anything and the reference catches that (:997, :1141), so there the
+        # faithful mode has nothing to do.
+        self.faithful_curiosity = bool(config.get("faithful_curiosity", False)) and not large
         # largest patch grid whose fp32 focal scores are kept in memory (see _workspace); tests lower it
         self.scores_in_memory_max_patches = int(config.get("focal_scores_in_memory_max_patches", 1536))
         # replay the per-shape launch sequence as one HIP graph after its first (eager) run

@@ -417,7 +417,7 @@ def _pe2d_table_loop(num_patches: int, dim: int) -> Tensor:
     return pe
 
 
-def forward_faithful_schedule(sd: SD, images: Tensor, exif, focus_strength: float = 1.5):
+def forward_faithful_schedule(sd: SD, images: Tensor, exif, focus_strength: float = 1.5, n_heads: int = 12):
     """Replays the call structure of a fresh reference ``forward`` (attribute
     ``_last_attention_weights`` unset, model.py:960-1113): backbone x2,
     iterative focal x3, ambient x2, with the Python position loop rebuilt in
@@ -430,7 +430,7 @@ def forward_faithful_schedule(sd: SD, images: Tensor, exif, focus_strength: floa
             _pe2d_table_loop(patches.size(1), patches.size(2))
         return iterative_focal_stream(sd, patches, n_it, focus_strength)
 
-    lhs = dinov2_forward(sd, images)                     # :973
+    lhs = dinov2_forward(sd, images, n_heads=n_heads)    # :973
     cls, patches = lhs[:, 0], lhs[:, 1:]
     ambient_stream(sd, cls)                              # :983 (dead)
     focal(patches)                                       # :1008 (dead)
@@ -441,6 +441,6 @@ def forward_faithful_schedule(sd: SD, images: Tensor, exif, focus_strength: floa
     if z.size(1) < 192:
         z = torch.cat([z, torch.zeros(z.size(0), 192 - z.size(1))], dim=1)
     depth, conf, _ = fusion_and_heads(sd, z)
-    lhs2 = dinov2_forward(sd, images)                    # :1095
+    lhs2 = dinov2_forward(sd, images, n_heads=n_heads)   # :1095
     focal(lhs2[:, 1:])                                   # :1112
     return depth, conf

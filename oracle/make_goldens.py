@@ -380,6 +380,72 @@ def g10_bare_focal_stream(ref):
     save("g10_bare_focal_stream", **arrays)
 
 
+def g11_large_backbone(ref):
+    """backbone_size='large' (src/model.py:807-809): 1024-wide tokens, 16 heads, every stream fed 1024 columns, the
+    guided path's per-call Linear(1024, 64) (:1421).  Two layers here, like the other full-width fixtures."""
+    from transformers import Dinov2Config, Dinov2Model
+    layers, grid = 2, 4
+    asked = []
+
+    def local(cls, name, *a, **k):
+        asked.append(name)
+        return Dinov2Model(Dinov2Config(hidden_size=1024, num_attention_heads=16, image_size=14 * grid,
+                                        num_hidden_layers=layers))
+    ref.Dinov2Model.from_pretrained = classmethod(local)
+    cfg = {"backbone_size": "large",
+           "cognitive_modules": ["ambient_stream", "iterative_focal_stream", "exif_prior_database"],
+           "focal_config": {"num_iterations": 3, "focus_strength": 1.5}}
+    with quiet():
+        model = ref.create_model(cfg, {"num_cameras": 71}).eval()
+    assert asked == ["facebook/dinov2-large"] and model.feature_dim == 1024
+    spec = reference_state_spec(hidden=1024, layers=layers, native_grid=grid, num_iterations=3, num_cameras=71)
+    ref_sd = model.state_dict()
+    assert list(ref_sd.keys()) == list(spec.keys()), (set(ref_sd) ^ set(spec))
+    for k, (shp, dt) in spec.items():
+        assert tuple(ref_sd[k].shape) == tuple(shp) and ref_sd[k].dtype == dt, k
+    model.load_state_dict(synth_state_dict(spec, seed=11), strict=True)
+    g = torch.Generator().manual_seed(111)
+    exif = {"camera_idx": torch.tensor([7, 60]), "focal_length": torch.tensor([28.0, 85.0]),
+            "aperture": torch.tensor([5.6, 1.4]), "iso": torch.tensor([800.0, 100.0])}
+    arrays = {"layers": layers, "native_grid": grid, "seed": 11, "hidden": 1024, "heads": 16}
+    for k, v in exif.items():
+        arrays["exif:" + k] = v.numpy()
+    created = []
+    real_linear = ref.nn.Linear
+
+    class Spy(real_linear):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            created.append(self)
+
+    for size in (56, 98):
+        x = torch.randn(2, 3, size, size, generator=g)
+        arrays[f"x{size}"] = x.numpy()
+        with torch.no_grad(), quiet() as log:
+            d, c, a = model(x, exif, return_attention=True)
+        arrays[f"curiosity_failures{size}"] = log.getvalue().count("calculation failed")
+        arrays[f"depth{size}"], arrays[f"conf{size}"], arrays[f"attn{size}"] = d.numpy(), c.numpy(), a.numpy()
+    arrays["history_untouched"] = bool((model.curiosity_module.exploration_history == 0).all()
+                                       and int(model.curiosity_module.history_pointer) == 0)
+    arrays["torch_seed"] = 999
+    torch.manual_seed(999)
+    ref.nn.Linear = Spy
+    try:
+        with torch.no_grad(), quiet() as log:
+            gd, gc, ga = model.forward_with_guidance(x, exif, "top-left", return_attention=True)
+    finally:
+        ref.nn.Linear = real_linear
+    # the curiosity module is 768 wide whatever the backbone (src/model.py:946-950): fed the 1024-wide CLS token
+    # it raises, the reference catches that and carries on with its default score (which reaches no output)
+    lines = [ln for ln in log.getvalue().splitlines() if "failed" in ln]
+    assert all(ln.startswith("Preliminary curiosity calculation failed") for ln in lines), lines
+    arrays["guided_log_failed_lines"] = len(lines)
+    assert len(created) == 1 and tuple(created[0].weight.shape) == (64, 1024)
+    arrays["guided_proj_w"], arrays["guided_proj_b"] = created[0].weight.detach().numpy(), created[0].bias.detach().numpy()
+    arrays["guided_depth"], arrays["guided_conf"], arrays["guided_attn"] = gd.numpy(), gc.numpy(), ga.numpy()
+    save("g11_large_backbone", **arrays)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
@@ -392,6 +458,7 @@ def main():
     g8_curiosity_state(ref)
     g9_single_patch(ref)
     g10_bare_focal_stream(ref)
+    g11_large_backbone(ref)
 
 
 if __name__ == "__main__":

@@ -275,3 +275,22 @@ def test_request_plan_groups_instructions_per_file():
     plan = h._plan(list(range(7)), paths, ins)
     assert plan == [((None,), [("a", [[3]]), ("c", [[4, 6]])]),
                     (("left", "right"), [("a", [[0], [1]]), ("b", [[2], [5]])])]
+
+
+def test_large_backbone_state_dict_matches_reference_layout():
+    """backbone_size='large' builds dinov2-large's geometry (24 layers, 16 heads, 1024 columns: reference
+    src/model.py:807-809) with the reference's state_dict keys, shapes and dtypes (the layout oracle/make_goldens.py
+    asserts against the real module); a strict load of such a state_dict succeeds on a CPU-built model."""
+    from cognitive_aim_depth_estimation_amd import create_model
+    from oracle.weights import reference_state_spec
+    cfg = {"backbone_size": "large", "cognitive_modules": ["ambient_stream", "iterative_focal_stream", "exif_prior_database"]}
+    full = create_model(dict(cfg, backbone_config={"image_size": 56}), {"num_cameras": 5})
+    assert (full.feature_dim, full.num_layers, full.num_heads) == (1024, 24, 16)
+    m = create_model(dict(cfg, backbone_config={"image_size": 56, "num_hidden_layers": 2}), {"num_cameras": 5})
+    spec = reference_state_spec(hidden=1024, layers=2, native_grid=4, num_iterations=3, num_cameras=5)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(spec.keys())
+    for k, (shape, dtype) in spec.items():
+        assert tuple(sd[k].shape) == tuple(shape) and sd[k].dtype == dtype, k
+    assert create_model(dict(cfg, backbone_size="huge", backbone_config={"image_size": 56, "num_hidden_layers": 1})
+                        ).feature_dim == 768          # unknown sizes fall back to base (:811-812)

@@ -197,3 +197,24 @@ def test_bare_focal_stream_variant_vs_reference():
     gd, gc, ga = O.forward_with_guidance(sd, x, exif, "bottom-left")
     for got, key in ((d, "depth"), (c, "conf"), (a, "attn"), (gd, "guided_depth"), (gc, "guided_conf"), (ga, "guided_attn")):
         assert np.allclose(got.numpy(), z[key], rtol=1e-4, atol=1e-7), key
+
+
+def test_large_backbone_vs_reference():
+    """backbone_size='large' (reference src/model.py:807-809: 1024 columns, 16 heads) against
+    tests/golden/g11_large_backbone.npz from the real reference (two layers, 4 x 4 native grid)."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g11_large_backbone.npz"))
+    hidden, heads = int(z["hidden"]), int(z["heads"])
+    sd = synth_state_dict(reference_state_spec(hidden=hidden, layers=int(z["layers"]), native_grid=int(z["native_grid"]),
+                                               num_iterations=3, num_cameras=71), seed=int(z["seed"]))
+    exif = {k: torch.from_numpy(z["exif:" + k]) for k in ("camera_idx", "focal_length", "aperture", "iso")}
+    for size in (56, 98):
+        x = torch.from_numpy(z[f"x{size}"])
+        d, c, a = O.forward(sd, x, exif, return_attention=True, n_heads=heads)
+        for got, key in ((d, "depth"), (c, "conf"), (a, "attn")):
+            assert np.allclose(got.numpy(), z[f"{key}{size}"], rtol=1e-4, atol=1e-7), (key, size)
+    proj = (torch.from_numpy(z["guided_proj_w"]), torch.from_numpy(z["guided_proj_b"]))
+    gd, gc, ga = O.forward_with_guidance(sd, x, exif, "top-left", temp_projection=proj, n_heads=heads)
+    for got, key in ((gd, "guided_depth"), (gc, "guided_conf"), (ga, "guided_attn")):
+        assert np.allclose(got.numpy(), z[key], rtol=2e-4, atol=1e-7), key
+    # the 768-wide curiosity module raises on 1024 columns before drawing anything; the reference catches it
+    assert int(z["curiosity_failures56"]) == 2 and bool(z["history_untouched"])
