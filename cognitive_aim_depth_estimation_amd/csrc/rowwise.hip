@@ -83,6 +83,90 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
   }
 }
 
+// The same gather one strip of patches at a time: a workgroup owns `seg` adjacent patches of one patch row of one
+// image, reads the 3 * p image-row segments they share as whole contiguous runs (converted to 16 bits in LDS), then
+// writes the patches' rows of `cols` as 16-byte pieces -- every image byte is fetched once, where the per-chunk gather
+// above touches each 128-byte line from several waves (2.2 x the image bytes in HBM reads at 518 pixels).
+// Work is dealt in units of (image row, 64 pixels), 16 units' loads in flight per wave; the position of column k inside
+// the LDS tile comes from a table built once per workgroup, so neither loop divides.
+constexpr int IM2COL_LDS_ELEMS = 22528;   // 44 KB of 16-bit pixels: 37 patches of 14 x 14 x 3
+constexpr int IM2COL_MAX_K = 1024;        // 3 p^2 handled by the strip kernel (p <= 18)
+constexpr int IM2COL_MAX_ROWS = 64;       // 3 p
+constexpr int IM2COL_THREADS = 512;       // 8 waves a workgroup: enough loads in flight per CU to cover HBM latency
+constexpr int IM2COL_WAVES = IM2COL_THREADS / 64;
+
+template <class T>
+__global__ __launch_bounds__(IM2COL_THREADS) void im2col_strip_kernel(const float* __restrict__ img, T* __restrict__ cols,
+                                                           int Himg, int Wimg, int gh, int gw, int p, int Kp, int seg) {
+  __shared__ __attribute__((aligned(16))) T tile[IM2COL_LDS_ELEMS];
+  __shared__ __attribute__((aligned(16))) unsigned short koff[IM2COL_MAX_K + 8];
+  __shared__ int rowoff[IM2COL_MAX_ROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px0 = blockIdx.x * seg, py = blockIdx.y, b = blockIdx.z;
+  const int np = min(seg, gw - px0);          // patches in this strip
+  const int wcols = np * p;                   // pixels per image-row segment
+  const int rows = 3 * p, K = rows * p, pp = p * p;
+  if (tid < rows) {
+    const int c = tid / p, ky = tid - c * p;
+    rowoff[tid] = (c * Himg + ky) * Wimg;
+  }
+  for (int k = tid; k < IM2COL_MAX_K + 8; k += IM2COL_THREADS) {
+    int v = 0;
+    if (k < K) {
+      const int c = k / pp, rem = k - c * pp, ky = rem / p, kx = rem - ky * p;
+      v = (c * p + ky) * wcols + kx;
+    }
+    koff[k] = (unsigned short)v;
+  }
+  __syncthreads();
+  const float* src = img + ((size_t)b * 3 * Himg + (size_t)py * p) * Wimg + (size_t)px0 * p;
+  {
+    const int nseg = (wcols + 63) >> 6, units = rows * nseg;
+    int r = 0, sg = wave;
+    while (sg >= nseg) { sg -= nseg; ++r; }
+    for (int u = wave; u < units; u += 16 * IM2COL_WAVES) {
+      float v[16];
+      int at[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int xx = sg * 64 + lane;
+        const bool ok = (u + IM2COL_WAVES * j < units) && xx < wcols;
+        at[j] = ok ? r * wcols + xx : -1;
+        v[j] = ok ? src[rowoff[ok ? r : 0] + xx] : 0.f;
+        sg += IM2COL_WAVES;
+        while (sg >= nseg) { sg -= nseg; ++r; }
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (at[j] >= 0) tile[at[j]] = (T)v[j];
+    }
+  }
+  __syncthreads();
+  const int chunks = Kp >> 3;
+  T* dst = cols + (((size_t)b * gh + py) * gw + px0) * Kp;
+  const int dpl = IM2COL_THREADS / chunks, dch = IM2COL_THREADS - dpl * chunks;
+  int pl = tid / chunks, ch = tid - pl * chunks;
+  for (; pl < np; pl += dpl) {
+    alignas(16) T o[8];
+    const int k = ch * 8;
+    if (k < IM2COL_MAX_K) {
+      const uint4 q = *reinterpret_cast<const uint4*>(koff + k);
+      const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int at = (int)((w[j >> 1] >> (16 * (j & 1))) & 0xffffu) + pl * p;
+        o[j] = (k + j < K) ? tile[at] : (T)0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (T)0.f;
+    }
+    *reinterpret_cast<uint4*>(dst + (size_t)pl * Kp + k) = *reinterpret_cast<const uint4*>(o);
+    ch += dch;
+    if (ch >= chunks) { ch -= chunks; ++pl; }
+  }
+}
+
 __global__ void cls_row_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ x,
                                int B, int T, int D) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -111,10 +195,19 @@ int cogaim_layernorm(const float* x, const float* gamma, const float* beta, void
 int cogaim_im2col(const float* images, void* cols, int B, int H, int W, int patch, int Kp, int dtype, void* stream) {
   const int gh = H / patch, gw = W / patch;
   if (B <= 0 || gh <= 0 || gw <= 0 || (Kp & 7) || Kp < 3 * patch * patch) return COGAIM_EINVAL;
+  if (dtype != 0 && dtype != 1) return COGAIM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int seg = IM2COL_LDS_ELEMS / (3 * patch * patch);       // patches per strip that fit the LDS tile
+  if (seg >= 1 && 3 * patch * patch <= IM2COL_MAX_K && gh <= 65535 && B <= 65535 && 3LL * H * W < (1LL << 31)) {
+    const int s = seg < gw ? seg : gw;
+    dim3 grid((gw + s - 1) / s, gh, B);
+    if (dtype == 0) hipLaunchKernelGGL(im2col_strip_kernel<__bf16>, grid, dim3(IM2COL_THREADS), 0, st, images, (__bf16*)cols, H, W, gh, gw, patch, Kp, s);
+    else hipLaunchKernelGGL(im2col_strip_kernel<_Float16>, grid, dim3(IM2COL_THREADS), 0, st, images, (_Float16*)cols, H, W, gh, gw, patch, Kp, s);
+    return COGAIM_LAUNCH_CHECK();
+  }
   const long long total = (long long)B * gh * gw * (Kp >> 3);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipStream_t st = (hipStream_t)stream;
   if (dtype == 0) hipLaunchKernelGGL(im2col_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, images, (__bf16*)cols, B, H, W, gh, gw, patch, Kp);
   else if (dtype == 1) hipLaunchKernelGGL(im2col_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, images, (_Float16*)cols, B, H, W, gh, gw, patch, Kp);
   else return COGAIM_EINVAL;

@@ -105,6 +105,26 @@ def test_patch_embed(dtype, size):
     assert torch.allclose(x, ref, rtol=1e-4, atol=1e-4), float((x - ref).abs().max())
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("H,W,p", [(56, 56, 14), (518, 518, 14), (1036, 1036, 14), (70, 98, 14), (45, 60, 14),
+                                   (64, 96, 16), (14, 14, 14), (200, 100, 100)])
+def test_im2col_exact(dtype, H, W, p):
+    """Patch gather (the A operand of the patch-embedding GEMM) against torch's unfold, bit for bit: strips of one and
+    of several LDS segments (1036 pixels: 74 patches a row), rectangular and cropped inputs (45 x 60 uses the top-left
+    42 x 56), another patch size, a single patch, and a patch too large for the strip kernel's LDS tile."""
+    di, tdt = DT[dtype]
+    B, K = 3, 3 * p * p
+    Kp = (K + 63) // 64 * 64
+    gh, gw = H // p, W // p
+    img = rnd(B, 3, H, W)
+    cols = torch.full((B * gh * gw, Kp), float("nan"), device="cuda", dtype=tdt)
+    call("cogaim_im2col", ptr(img), ptr(cols), B, H, W, p, Kp, di, stream_ptr())
+    ref = torch.nn.functional.unfold(img[:, :, :gh * p, :gw * p], kernel_size=p, stride=p)      # [B, K, gh * gw]
+    ref = ref.transpose(1, 2).reshape(B * gh * gw, K).to(tdt)
+    assert torch.equal(cols[:, :K], ref)
+    assert bool((cols[:, K:] == 0).all())
+
+
 @pytest.mark.parametrize("out", [0, 1, 2])
 @pytest.mark.parametrize("M,D", [(7, 768), (1001, 768), (33, 64), (5, 1024)])
 def test_layernorm(out, M, D):
