@@ -18,7 +18,7 @@ P, I, F, LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 # name -> argument types (all return int); mirrors include/cogaim.h
 SIGNATURES = {
     "cogaim_version": [],
-    "cogaim_preprocess_rgb8": [P, I, I, LL, P, P, I, P, P, I, P, P, P, I, I, P],
+    "cogaim_preprocess_rgb8": [P, I, I, LL, I, P, P, I, P, P, I, P, P, P, I, I, P],
     "cogaim_gemm_workspace_bytes": [],
     "cogaim_set_gemm_algo": [I],
     "cogaim_im2col": [P, P, I, I, I, I, I, I, P],
@@ -65,7 +65,10 @@ class CogaimError(RuntimeError):
     pass
 
 
-def lib() -> C.CDLL:
+def lib() -> C.PyDLL:
+    """The library handle.  Loaded with ctypes.PyDLL: every entry point only enqueues work on a stream and returns in
+    microseconds, and a call that dropped the interpreter lock would have to win it back from whatever other thread
+    holds it (decode workers of the batch loop), which costs far more than the call."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
@@ -73,7 +76,7 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with "
                 "`python -m cognitive_aim_depth_estimation_amd.build` (hipcc, gfx950). "
                 "This package has no CPU or eager fallback.")
-        handle = C.CDLL(LIB_PATH)
+        handle = C.PyDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes = args

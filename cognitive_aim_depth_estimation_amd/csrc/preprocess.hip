@@ -17,7 +17,7 @@ __device__ __forceinline__ int clip8(int v) {
 // tmp[y][xx][c] = resample of src row y at output column xx.  One thread per (xx, y); threads of a wave
 // walk neighbouring output columns, whose source windows overlap (reads served from L1/L2).
 __global__ __launch_bounds__(256) void resize_rows_kernel(const uint8_t* __restrict__ src, long long src_row_bytes,
-                                                          int src_h, const int* __restrict__ bounds,
+                                                          int px, int src_h, const int* __restrict__ bounds,
                                                           const int* __restrict__ coefs, int ksize,
                                                           uint8_t* __restrict__ tmp, int out_w) {
   const int xx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -25,11 +25,12 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(const uint8_t* __restr
   if (xx >= out_w || y >= src_h) return;
   const int x0 = bounds[2 * xx], n = bounds[2 * xx + 1];
   const int* k = coefs + (size_t)xx * ksize;
-  const uint8_t* p = src + (size_t)y * src_row_bytes + (size_t)x0 * 3;
+  const uint8_t* p = src + (size_t)y * src_row_bytes + (size_t)x0 * px;      // px bytes per source pixel, R G B first
   int s0 = 1 << (PREC - 1), s1 = s0, s2 = s0;
   for (int t = 0; t < n; ++t) {
     const int w = k[t];
-    s0 += p[3 * t] * w; s1 += p[3 * t + 1] * w; s2 += p[3 * t + 2] * w;
+    s0 += p[0] * w; s1 += p[1] * w; s2 += p[2] * w;
+    p += px;
   }
   uint8_t* q = tmp + ((size_t)y * out_w + xx) * 3;
   q[0] = (uint8_t)clip8(s0); q[1] = (uint8_t)clip8(s1); q[2] = (uint8_t)clip8(s2);
@@ -65,18 +66,20 @@ __global__ __launch_bounds__(256) void resize_cols_normalize_kernel(const uint8_
 
 extern "C" {
 
-// src: uint8 [src_h, src_w, 3] with src_row_bytes between rows; xbounds/ybounds int32 [out, 2] = (first
+// src: uint8 [src_h, src_w, src_pixel_bytes] (3 = packed RGB, 4 = RGBX as the host imaging library keeps it in
+// memory; the fourth byte is ignored) with src_row_bytes between rows; xbounds/ybounds int32 [out, 2] = (first
 // source index, taps), xcoefs/ycoefs int32 [out, xk|yk] 22-bit weights; tmp: uint8 [src_h, out_w, 3] scratch;
 // lut: fp32 [3, 256]; dst: fp32 [3, out_h, out_w].
-int cogaim_preprocess_rgb8(const void* src, int src_h, int src_w, long long src_row_bytes, const int* xbounds,
-                           const int* xcoefs, int xk, const int* ybounds, const int* ycoefs, int yk, void* tmp,
+int cogaim_preprocess_rgb8(const void* src, int src_h, int src_w, long long src_row_bytes, int src_pixel_bytes,
+                           const int* xbounds, const int* xcoefs, int xk, const int* ybounds, const int* ycoefs, int yk, void* tmp,
                            const float* lut, float* dst, int out_h, int out_w, void* stream) {
-  if (src_h <= 0 || src_w <= 0 || out_h <= 0 || out_w <= 0 || xk <= 0 || yk <= 0 || src_row_bytes < 3ll * src_w ||
+  if (src_h <= 0 || src_w <= 0 || out_h <= 0 || out_w <= 0 || xk <= 0 || yk <= 0 ||
+      (src_pixel_bytes != 3 && src_pixel_bytes != 4) || src_row_bytes < (long long)src_pixel_bytes * src_w ||
       src_h > 65535 || out_h > 65535)
     return COGAIM_EINVAL;
   const dim3 block(256);
   hipLaunchKernelGGL(resize_rows_kernel, dim3((out_w + 255) / 256, src_h), block, 0, (hipStream_t)stream,
-                     (const uint8_t*)src, src_row_bytes, src_h, xbounds, xcoefs, xk, (uint8_t*)tmp, out_w);
+                     (const uint8_t*)src, src_row_bytes, src_pixel_bytes, src_h, xbounds, xcoefs, xk, (uint8_t*)tmp, out_w);
   hipLaunchKernelGGL(resize_cols_normalize_kernel, dim3((out_w + 255) / 256, out_h), block, 0, (hipStream_t)stream,
                      (const uint8_t*)tmp, out_w, ybounds, ycoefs, yk, lut, dst, out_h);
   return COGAIM_LAUNCH_CHECK();

@@ -258,6 +258,6 @@ int cogaim_heatmap_postprocess(const float* attn, float* out, int B, int N, int 
   return COGAIM_LAUNCH_CHECK();
 }
 
-int cogaim_version() { return 2; }
+int cogaim_version() { return 3; }
 
 }  // extern "C"

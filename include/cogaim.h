@@ -36,9 +36,11 @@ int cogaim_version(void);
  * (22 fractional bits, support widened by the shrink factor), horizontal pass into an 8-bit intermediate, then
  * vertical pass, each (2^21 + sum) >> 22 clipped to 0..255 -- reproduced bit for bit.  The caller supplies the
  * per-axis tables ([out, 2] = first source index and tap count; [out, k] weights) and a [3, 256] fp32 table of
- * (v / 255 - mean) / std.  src uint8 [src_h, src_w, 3] (row pitch src_row_bytes), tmp uint8 [src_h, out_w, 3]
+ * (v / 255 - mean) / std.  src uint8 [src_h, src_w, src_pixel_bytes] (row pitch src_row_bytes; 3 bytes per pixel =
+ * packed RGB, 4 = RGBX, the layout Pillow keeps an RGB image in, fourth byte ignored), tmp uint8 [src_h, out_w, 3]
  * scratch, dst fp32 [3, out_h, out_w]. */
-int cogaim_preprocess_rgb8(const void* src, int src_h, int src_w, long long src_row_bytes, const int* xbounds,
+int cogaim_preprocess_rgb8(const void* src, int src_h, int src_w, long long src_row_bytes, int src_pixel_bytes,
+                           const int* xbounds,
                            const int* xcoefs, int xk, const int* ybounds, const int* ycoefs, int yk, void* tmp,
                            const float* lut, float* dst, int out_h, int out_w, void* stream);
 

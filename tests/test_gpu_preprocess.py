@@ -60,3 +60,32 @@ def test_grayscale_and_rgba_inputs_follow_the_host_conversion():
     rgba = PIL.fromarray(rng.integers(0, 256, size=(40, 50, 4), dtype=np.uint8), "RGBA")
     for im in (gray, rgba):
         assert torch.equal(pre(im).cpu(), preprocess_image(im, (28, 28)))
+
+
+def test_batch_of_rgbx_views_equals_packed_rgb(tmp_path):
+    """The batch loop hands the kernel Pillow's own RGBX memory (4 bytes a pixel, zero-copy view from
+    CognitiveAimInference._decode) where it can and packed RGB copies where it cannot: same pixels, same bits."""
+    from cognitive_aim_depth_estimation_amd.inference import CognitiveAimInference
+    rng = np.random.default_rng(8)
+    pre = DevicePreprocessor((56, 70), "cuda")
+    sizes = ((90, 120), (33, 47), (518, 518), (64, 200))
+    rgb = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in sizes]
+    rgbx = [np.concatenate([a, rng.integers(0, 256, size=a.shape[:2] + (1,), dtype=np.uint8)], axis=2) for a in rgb]
+    mixed = [rgbx[0], rgb[1], rgbx[2], rgbx[3]]
+    a = pre.batch(rgb, torch.zeros(4, 3, 56, 70, device="cuda")).clone()
+    b = pre.batch(mixed, torch.zeros(4, 3, 56, 70, device="cuda")).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    for i, arr in enumerate(rgb):
+        assert torch.equal(a[i].cpu(), preprocess_image(PIL.fromarray(arr, "RGB"), (56, 70)))
+    # _decode: a view of the decoder's memory for an RGB file, a packed copy for a converted palette file; same pixels
+    p_rgb, p_pal = str(tmp_path / "a.png"), str(tmp_path / "b.png")
+    PIL.fromarray(rgb[0], "RGB").save(p_rgb)
+    PIL.fromarray(rgb[0], "RGB").convert("P").save(p_pal)
+    arr, exif, size = CognitiveAimInference._decode(None, p_rgb)
+    assert size == (120, 90) and exif is None and np.array_equal(arr[:, :, :3], rgb[0])
+    import importlib.util
+    if importlib.util.find_spec("pyarrow") is not None and hasattr(PIL.Image, "__arrow_c_array__"):
+        assert arr.shape == (90, 120, 4) and not arr.flags.owndata
+    arr2, _, _ = CognitiveAimInference._decode(None, p_pal)
+    assert np.array_equal(arr2[:, :, :3], np.asarray(PIL.open(p_pal).convert("RGB")))

@@ -21,7 +21,7 @@ for (h, w), S in (((3024, 4032), 518), ((1080, 1920), 518), ((480, 640), 518), (
     n = 50
     e0.record()
     for _ in range(n):
-        call("cogaim_preprocess_rgb8", ptr(src), h, w, w * 3, ptr(xb), ptr(xc), xk, ptr(yb), ptr(yc), yk,
+        call("cogaim_preprocess_rgb8", ptr(src), h, w, w * 3, 3, ptr(xb), ptr(xc), xk, ptr(yb), ptr(yc), yk,
              ptr(pre._tmp), ptr(pre._lut), ptr(out), S, S, stream_ptr())
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / n * 1e3
