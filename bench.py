@@ -2,15 +2,15 @@
 """Throughput of the Cognitive-Aim depth forward pass on MI355X.
 
 One step = one `model.forward(images, exif)` over a resident synthetic batch of
-32 images at 518x518 per GPU (BASELINE config 2: full_cognitive, B=32, 1 GPU;
-config 4 is the same per-GPU batch on 8 GPUs, image-sharded, with one RCCL
+32 images at 518x518 per GPU (the reference's headline configuration: full_cognitive, B=32, 1 GPU;
+its 8-GPU form is the same per-GPU batch, image-sharded, with one RCCL
 all-gather of the per-image [depth, confidence] pairs per step).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python bench.py --gpus N ...            (starts the N rank processes itself; fails if fewer GPUs are visible)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-The headline operand type is bf16 (BASELINE config 2); fp16 is timed beside it (`by_dtype`), each with its
+The headline operand type is bf16 (as that configuration names it); fp16 is timed beside it (`by_dtype`), each with its
 parity against the CPU oracle on the same images.
 
 Prints ONE JSON line (rank 0).
@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--backbone", default="base", choices=["base", "large"],
                     help="backbone_size of the model config (base = ViT-B/14, the headline; large = ViT-L/14)")
     ap.add_argument("--dtype", default=os.environ.get("COGAIM_DTYPE", "bf16"), choices=["fp16", "bf16"],
-                    help="headline operand type (BASELINE config 2 is bf16); the other one is timed beside it")
+                    help="headline operand type (the headline configuration is bf16); the other one is timed beside it")
     ap.add_argument("--streams", type=int, default=0,
                     help="sub-batches the model runs on streams of its own (0 = the model's default, 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -268,7 +268,7 @@ def main():
 
     if not args.no_second_dtype:
         # the other 16-bit operand type through the same steps and the same bracket, outside the headline's timed
-        # region: BASELINE names bf16; fp16 has the same MFMA rate, 3 more significand bits and 8 fewer exponent bits
+        # region: the headline configuration names bf16; fp16 has the same MFMA rate, 3 more significand bits and 8 fewer exponent bits
         other = "fp16" if args.dtype == "bf16" else "bf16"
         del model
         torch.cuda.empty_cache()
