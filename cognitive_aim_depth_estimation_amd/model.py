@@ -43,6 +43,7 @@ _FLAG_WORDS = 64
 _MAX_ITERATIONS = 48
 _FLAG_RANGE = 60        # a 16-bit store exceeded the fp16 range (fp16 operands only)
 _FLAG_CAMERA = 63       # camera_idx outside the embedding table
+_FLAG_SNAPSHOTS = 4     # host copies of the flag words in flight per workspace (bounds how far the host runs ahead)
 
 
 # --------------------------------------------------------------------------
@@ -443,7 +444,10 @@ class CognitiveAimModel(nn.Module):
             "part": torch.empty(B * nblk * N, **f32), "attn": torch.empty(B, N, **f32),
             "scale": torch.empty(2, B, N, **f32), "stats": torch.empty(B, 2, device=dev, dtype=torch.float64),
             "flags": torch.zeros(_FLAG_WORDS, device=dev, dtype=torch.int32),
-            "flags_host": torch.zeros(_FLAG_WORDS, dtype=torch.int32).pin_memory(), "flags_event": torch.cuda.Event(),
+            # host snapshots of the flag words, one per forward, examined when their copy has landed
+            "flag_ring": [{"host": torch.zeros(_FLAG_WORDS, dtype=torch.int32).pin_memory(), "event": torch.cuda.Event(),
+                           "pending": False} for _ in range(_FLAG_SNAPSHOTS)],
+            "flag_next": 0,
             "u": torch.empty(B, N, **f32), "usum": torch.empty(B, **f32),
             "wt": torch.empty(B, D, **f32), "w": torch.empty(B, D, **f32),
             "wtpart": torch.empty(B * ((N + call("cogaim_weighted_tokens_rows") - 1)
@@ -556,36 +560,54 @@ class CognitiveAimModel(nn.Module):
         evaluated on device; it cannot fire for any grid larger than 1x1 (the centre bias alone
         has variance far above the threshold), so a set flag is reported, not emulated.
 
-        The flags are copied to pinned host memory asynchronously and examined at the next
-        call on this workspace or in ``synchronize()``: no host stall inside the forward.  A caller
-        that runs a single forward and wants these conditions raised calls ``model.synchronize()``
-        after it.  An out-of-range camera index additionally makes that image's depth and
-        confidence NaN, so its result cannot pass for a prediction."""
-        self._examine_flags(ws)
-        ws["flags_host"].copy_(ws["flags"], non_blocking=True)
-        ws["flags_event"].record()
-        ws["flags_pending"] = True
+        Every forward copies the flag words to one of a few pinned host snapshots asynchronously; a snapshot is
+        examined by a later call on this workspace once its copy has landed, or by ``synchronize()``: the forward
+        never waits for the device (waiting for the previous forward's snapshot, as a single snapshot would need,
+        leaves the GPU idle between two forwards until the host has issued the next one).  A caller that wants these
+        conditions raised at a definite point calls ``model.synchronize()``.  An out-of-range camera index
+        additionally makes that image's depth and confidence NaN, so its result cannot pass for a prediction."""
+        self._examine_flags(ws, wait=False)
+        slot = ws["flag_ring"][ws["flag_next"]]
+        if slot["pending"]:                    # the host is a whole ring of forwards ahead of the device
+            self._examine_flags(ws, wait=True)
+        slot["host"].copy_(ws["flags"], non_blocking=True)
+        slot["event"].record()
+        slot["pending"] = True
+        ws["flag_next"] = (ws["flag_next"] + 1) % _FLAG_SNAPSHOTS
 
     def _examine_flags(self, ws, wait=True):
-        if ws.get("flags_pending"):
+        """Oldest snapshot first; without `wait`, stops at the first one whose copy has not landed yet."""
+        ring, first = ws["flag_ring"], ws["flag_next"]
+        for j in range(_FLAG_SNAPSHOTS):
+            slot = ring[(first + j) % _FLAG_SNAPSHOTS]
+            if not slot["pending"]:
+                continue
             if wait:
-                ws["flags_event"].synchronize()
-            elif not ws["flags_event"].query():
+                slot["event"].synchronize()
+            elif not slot["event"].query():
                 return
-            ws["flags_pending"] = False
-            host = ws["flags_host"]
+            slot["pending"] = False
+            host = slot["host"]
+            err = None
             if int(host[_FLAG_CAMERA]):
                 ws["flags"][_FLAG_CAMERA] = 0
-                raise IndexError("camera_idx out of range in an earlier forward (index out of range in self); "
+                err = IndexError("camera_idx out of range in an earlier forward (index out of range in self); "
                                  "depth and confidence of that image are NaN")
-            if int(host[_FLAG_RANGE]):
+            elif int(host[_FLAG_RANGE]):
                 ws["flags"][_FLAG_RANGE] = 0
-                raise OverflowError("an activation exceeded the fp16 range (65504) in an earlier forward and was "
+                err = OverflowError("an activation exceeded the fp16 range (65504) in an earlier forward and was "
                                     "stored as inf: results of that call are not valid.  Build the model with "
                                     "compute_dtype='bf16' (same speed, fp32 exponent range) for these weights")
-            if ws["N"] > 1 and bool(host[: self.num_iterations].any()):
-                raise RuntimeError("focal attention variance fell below 1e-6 in an earlier forward: the "
+            elif ws["N"] > 1 and bool(host[: self.num_iterations].any()):
+                err = RuntimeError("focal attention variance fell below 1e-6 in an earlier forward: the "
                                    "reference's degenerate-attention fallbacks (src/model.py:242-257) are not built")
+            if err is not None:
+                # reported once: younger snapshots were taken before the device words were cleared just above
+                for other in ring:
+                    if other["pending"]:
+                        other["event"].synchronize()
+                        other["pending"] = False
+                raise err
 
     def synchronize(self):
         """Waits for all queued work of this model and raises any deferred device-side condition."""
