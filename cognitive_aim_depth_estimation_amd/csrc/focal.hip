@@ -23,21 +23,55 @@ static __device__ __align__(256) float scratch[COGAIM_WT_STATIC_FLOATS];
 namespace {
 
 // One wave per token row (no per-element index arithmetic), 16-byte loads, 8-byte stores.
-template <class T>
+// NV > 0: D = 256 * NV, every lane owns exactly NV float4 of a row; a wave takes token n of FOUR images, so the row
+// of the position table is fetched once for the four (the table is read once per image otherwise: as many bytes
+// again as the tokens) and all of the loads are requested before the first one is used.  NV = 0: any D (a multiple
+// of 4), one wave per (image, token).
+template <class T, int NV>
 __global__ __launch_bounds__(256) void focal_prep_kernel(const float* __restrict__ tok, long long tok_stride_b,
                                                          const float* __restrict__ scale, const float* __restrict__ pe,
                                                          T* __restrict__ out, int B, int N, int D) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= B * N) return;
-  const int b = row / N, n = row - b * N;
-  const float4* x4 = reinterpret_cast<const float4*>(tok + b * tok_stride_b + (size_t)n * D);
-  const float4* p4 = reinterpret_cast<const float4*>(pe + (size_t)n * D);
-  Half4<T>* o4 = reinterpret_cast<Half4<T>*>(out + (size_t)row * D);
-  const float s = scale ? scale[row] : 1.0f;
-  for (int c = lane; c < (D >> 2); c += 64) {
-    const float4 x = x4[c], p = p4[c];
-    o4[c] = to_half4<T>(x.x * s + p.x, x.y * s + p.y, x.z * s + p.z, x.w * s + p.w);
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if constexpr (NV > 0) {
+    const int groups = (B + 3) >> 2;
+    if (item >= N * groups) return;
+    const int n = item / groups, b0 = (item - n * groups) * 4;
+    const float4* p4 = reinterpret_cast<const float4*>(pe + (size_t)n * D);
+    float4 p[NV], x[4][NV];
+    float s[4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) p[i] = p4[lane + 64 * i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int b = min(b0 + j, B - 1);
+      const float4* x4 = reinterpret_cast<const float4*>(tok + b * tok_stride_b + (size_t)n * D);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) x[j][i] = x4[lane + 64 * i];
+      s[j] = scale ? scale[(size_t)b * N + n] : 1.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (b0 + j < B) {
+        Half4<T>* o4 = reinterpret_cast<Half4<T>*>(out + ((size_t)(b0 + j) * N + n) * D);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          o4[lane + 64 * i] = to_half4<T>(x[j][i].x * s[j] + p[i].x, x[j][i].y * s[j] + p[i].y, x[j][i].z * s[j] + p[i].z,
+                                          x[j][i].w * s[j] + p[i].w);
+      }
+    }
+  } else {
+    const int row = item;
+    if (row >= B * N) return;
+    const int b = row / N, n = row - b * N;
+    const float4* x4 = reinterpret_cast<const float4*>(tok + b * tok_stride_b + (size_t)n * D);
+    const float4* p4 = reinterpret_cast<const float4*>(pe + (size_t)n * D);
+    Half4<T>* o4 = reinterpret_cast<Half4<T>*>(out + (size_t)row * D);
+    const float s = scale ? scale[row] : 1.0f;
+    for (int c = lane; c < (D >> 2); c += 64) {
+      const float4 x = x4[c], p = p4[c];
+      o4[c] = to_half4<T>(x.x * s + p.x, x.y * s + p.y, x.z * s + p.z, x.w * s + p.w);
+    }
   }
 }
 
@@ -323,15 +357,28 @@ __global__ __launch_bounds__(256) void weighted_tokens_partial_kernel(const floa
   part += (size_t)blockIdx.z * gridDim.y * nchunk * D;
   for (int c = threadIdx.x * 4; c < D; c += 1024) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int n = n0; n < n1; ++n) {
-      float4 x = *reinterpret_cast<const float4*>(tb + (size_t)n * D + c);
-      const float wn = w[(size_t)b * N + n];
-      if (scale) { const float s = scale[(size_t)b * N + n]; x.x *= s; x.y *= s; x.z *= s; x.w *= s; }
-      if (pe) {
-        const float4 p = *reinterpret_cast<const float4*>(pe + (size_t)n * D + c);
-        x.x += p.x; x.y += p.y; x.z += p.z; x.w += p.w;
+    // eight rows' loads are requested together (a block is 32 rows of one image: few blocks per CU, so the loop is
+    // bound by how many loads each thread keeps in flight); rows are added in ascending order whatever the batching
+    for (int m0 = n0; m0 < n1; m0 += 8) {
+      float4 x[8], p[8];
+      float wn[8], sc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int n = min(m0 + j, n1 - 1);
+        x[j] = *reinterpret_cast<const float4*>(tb + (size_t)n * D + c);
+        wn[j] = w[(size_t)b * N + n];
+        sc[j] = scale ? scale[(size_t)b * N + n] : 1.0f;
+        p[j] = pe ? *reinterpret_cast<const float4*>(pe + (size_t)n * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      acc.x += wn * x.x; acc.y += wn * x.y; acc.z += wn * x.z; acc.w += wn * x.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (m0 + j < n1) {
+          float4 v = x[j];
+          if (scale) { v.x *= sc[j]; v.y *= sc[j]; v.z *= sc[j]; v.w *= sc[j]; }
+          if (pe) { v.x += p[j].x; v.y += p[j].y; v.z += p[j].z; v.w += p[j].w; }
+          acc.x += wn[j] * v.x; acc.y += wn[j] * v.y; acc.z += wn[j] * v.z; acc.w += wn[j] * v.w;
+        }
+      }
     }
     *reinterpret_cast<float4*>(part + ((size_t)b * nchunk + chunk) * D + c) = acc;
   }
@@ -376,12 +423,21 @@ int cogaim_focal_prep(const float* tok, long long tok_stride_b, const float* sca
                       int N, int D, int dtype, void* stream) {
   if (B <= 0 || N <= 0 || (D & 3)) return COGAIM_EINVAL;
   if ((long long)B * N >= (1ll << 31)) return COGAIM_EINVAL;
-  const int g = (B * N + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == 0) hipLaunchKernelGGL(focal_prep_kernel<__bf16>, dim3(g), dim3(256), 0, st, tok, tok_stride_b, scale, pe, (__bf16*)out, B, N, D);
-  else if (dtype == 1) hipLaunchKernelGGL(focal_prep_kernel<_Float16>, dim3(g), dim3(256), 0, st, tok, tok_stride_b, scale, pe, (_Float16*)out, B, N, D);
-  else return COGAIM_EINVAL;
-  return COGAIM_LAUNCH_CHECK();
+  if (dtype != 0 && dtype != 1) return COGAIM_EINVAL;
+  int g;                  // workgroups of four waves: a wave per (token, four images) or per (image, token)
+#define COGAIM_PREP(NV_)                                                                                                     \
+  {                                                                                                                         \
+    if (dtype == 0) hipLaunchKernelGGL((focal_prep_kernel<__bf16, NV_>), dim3(g), dim3(256), 0, st, tok, tok_stride_b, scale, pe, (__bf16*)out, B, N, D); \
+    else hipLaunchKernelGGL((focal_prep_kernel<_Float16, NV_>), dim3(g), dim3(256), 0, st, tok, tok_stride_b, scale, pe, (_Float16*)out, B, N, D); \
+    return COGAIM_LAUNCH_CHECK();                                                                                            \
+  }
+  g = (N * ((B + 3) / 4) + 3) / 4;
+  if (D == 768) COGAIM_PREP(3)
+  if (D == 1024) COGAIM_PREP(4)
+  g = (B * N + 3) / 4;
+  COGAIM_PREP(0)
+#undef COGAIM_PREP
 }
 
 // Row statistics of the log2-domain scores + per-row-block column sums of the softmax.
@@ -416,7 +472,9 @@ int cogaim_focal_attention_vector(const float* part, const float* center_bias, f
                                   int nblk, void* stream) {
   if (B <= 0 || N <= 0) return COGAIM_EINVAL;
   if (nblk <= 0) nblk = (N + CS_ROWS - 1) / CS_ROWS;
-  // the reduced column sums are staged in `a` itself (the kernel reads a[b][c] before overwriting it)
+  // the reduced column sums are staged in `a` itself (the kernel reads a[b][c] before overwriting it); the reduction
+  // stays a launch of its own: one thread per column over a wide grid takes 8 us, folded into the one-workgroup-
+  // per-image kernel behind it 40 us (43 dependent-latency loads per column on 16 CUs)
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, part, nblk, a, N);
   hipLaunchKernelGGL(focal_attention_vector_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)a,
                      center_bias, a, stats, scale_in, scale_out, focus_strength, N);

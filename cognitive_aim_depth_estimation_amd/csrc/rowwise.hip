@@ -55,6 +55,65 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// Sum over the 64 lanes, result in every lane, without the LDS permute path: rotations inside rows of 16 lanes
+// (DPP), then the two row-swap instructions of gfx950.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define COGAIM_ROR(ctrl_) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl_, 0xf, 0xf, false))
+  v += COGAIM_ROR(0x128);   // row_ror:8
+  v += COGAIM_ROR(0x124);   // row_ror:4
+  v += COGAIM_ROR(0x122);   // row_ror:2
+  v += COGAIM_ROR(0x121);   // row_ror:1
+#undef COGAIM_ROR
+  unsigned u = __float_as_uint(v);
+  auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // rows (0,1) and (2,3) meet
+  v = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+  u = __float_as_uint(v);
+  auto s32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // the two halves meet
+  return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+}
+
+// LayerNorm for D = 256 * NV (768: NV = 3, 1024: NV = 4): every lane holds exactly NV float4 of its row, so there is
+// no per-chunk predicate; gamma / beta are requested before the reductions so that their latency lies under them.
+template <class OutT, bool F32OUT, int NV>
+__global__ __launch_bounds__(256) void layernorm_fixed_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, void* __restrict__ out,
+                                                              int M, float eps) {
+  constexpr int D = 256 * NV;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+  float4 v[NV], g[NV], b[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = xr[lane + 64 * i];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    g[i] = reinterpret_cast<const float4*>(gamma)[lane + 64 * i];
+    b[i] = reinterpret_cast<const float4*>(beta)[lane + 64 * i];
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum_dpp(sum) * (1.0f / (float)D);
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  const float rstd = rsqrtf(wave_sum_dpp(sq) * (1.0f / (float)D) + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    const float y0 = v[i].x * rstd * g[i].x + b[i].x, y1 = v[i].y * rstd * g[i].y + b[i].y;
+    const float y2 = v[i].z * rstd * g[i].z + b[i].z, y3 = v[i].w * rstd * g[i].w + b[i].w;
+    if constexpr (F32OUT)
+      reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * D)[c] = make_float4(y0, y1, y2, y3);
+    else
+      reinterpret_cast<Half4<OutT>*>(reinterpret_cast<OutT*>(out) + (size_t)row * D)[c] = to_half4<OutT>(y0, y1, y2, y3);
+  }
+}
+
 // images [B,3,H,W] fp32 -> cols [B*gh*gw, Kp] 16-bit, column c*p*p + ky*p + kx, zero padded to Kp.
 template <class T>
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, T* __restrict__ cols, int B,
@@ -185,6 +244,17 @@ int cogaim_layernorm(const float* x, const float* gamma, const float* beta, void
   if (M <= 0 || (D & 3) || D > 256 * LN_MAX_VEC) return COGAIM_EINVAL;
   dim3 grid((M + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
+  if (out_dtype < 0 || out_dtype > 2) return COGAIM_EINVAL;
+#define COGAIM_LN_FIXED(NV_)                                                                                                   \
+  {                                                                                                                           \
+    if (out_dtype == 0) hipLaunchKernelGGL((layernorm_fixed_kernel<__bf16, false, NV_>), grid, block, 0, st, x, gamma, beta, out, M, eps); \
+    else if (out_dtype == 1) hipLaunchKernelGGL((layernorm_fixed_kernel<_Float16, false, NV_>), grid, block, 0, st, x, gamma, beta, out, M, eps); \
+    else hipLaunchKernelGGL((layernorm_fixed_kernel<float, true, NV_>), grid, block, 0, st, x, gamma, beta, out, M, eps);      \
+    return COGAIM_LAUNCH_CHECK();                                                                                              \
+  }
+  if (D == 768) COGAIM_LN_FIXED(3)
+  if (D == 1024) COGAIM_LN_FIXED(4)
+#undef COGAIM_LN_FIXED
   if (out_dtype == 0) hipLaunchKernelGGL((layernorm_kernel<__bf16, false>), grid, block, 0, st, x, gamma, beta, out, M, D, eps);
   else if (out_dtype == 1) hipLaunchKernelGGL((layernorm_kernel<_Float16, false>), grid, block, 0, st, x, gamma, beta, out, M, D, eps);
   else if (out_dtype == 2) hipLaunchKernelGGL((layernorm_kernel<float, true>), grid, block, 0, st, x, gamma, beta, out, M, D, eps);
