@@ -504,6 +504,7 @@ constexpr int STAGE_BYTES = 2 * OP_BYTES;     // 64 KiB
 
 #ifdef COGAIM_STAMPS
 __device__ long long g_stamp_buf[256 * 12 * 4];
+__device__ long long g_clock_buf[4 * 256 * 4];  // [problem class][workgroup]: shader clock and 100-MHz clock at entry and exit
 #endif
 int g_gemm_slice_cap = 0;   // changed only by builds with -DCOGAIM_TOOLS (tools/gemm_bench.py)
 int g_gemm_quads = 1;       // 0: K-split + fix-up launch for every partial last round (ditto)
@@ -637,6 +638,9 @@ int cogaim_gemm_patch_embed(const void* cols, const void* W, const float* bias, 
 #ifdef COGAIM_STAMPS
 int cogaim_debug_stamps(void* dst) {
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamp_buf), sizeof(long long) * 256 * 12 * 4) == hipSuccess ? 0 : -1;
+}
+int cogaim_debug_clock(void* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_clock_buf), sizeof(long long) * 4 * 256 * 4) == hipSuccess ? 0 : -1;
 }
 #endif
 int cogaim_set_gemm_algo(int algo) {

@@ -80,6 +80,14 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
   const bool has_slice = !sc.quads && sb >= 0 && sb < sc.n_split * sc.slices;
   const int n_items = full_per_block + (has_slice ? 1 : 0);
   if (n_items == 0) return;
+#ifdef COGAIM_STAMPS
+  // problem class of the diagnostic clock stamps: 0 = N 3072 (fc1), 1 = N 2304 (QKV), 2 = K 3072 (fc2), 3 = the rest
+  const int cclass = g.N == 3072 ? 0 : (g.N == 2304 ? 1 : (g.K == 3072 ? 2 : 3));
+  if (tid == 0) {
+    g_clock_buf[(cclass * 256 + bid) * 4 + 0] = __builtin_amdgcn_s_memtime();
+    g_clock_buf[(cclass * 256 + bid) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   const T* const A0 = reinterpret_cast<const T*>(g.A);
   const T* const W0 = reinterpret_cast<const T*>(g.W);
 
@@ -325,6 +333,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
 #endif
   }
   if (wr == 0) BARRIER();          // match the extra barrier of the trailing group: both groups are level again
+#ifdef COGAIM_STAMPS
+  if (tid == 0) {
+    g_clock_buf[(cclass * 256 + bid) * 4 + 2] = __builtin_amdgcn_s_memtime();
+    g_clock_buf[(cclass * 256 + bid) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 
   // ---- quadrant items: the partial last round ------------------------------------------------------
   // Each leftover tile goes to four workgroups (on one XCD: they stream the same panels); a workgroup runs ONE
