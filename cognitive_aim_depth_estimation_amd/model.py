@@ -252,7 +252,8 @@ class CognitiveAimModel(nn.Module):
             raise ValueError(f"compute_dtype must be one of {sorted(_DTYPES)}")
         # Batches of 2 x 8 images or more are run as `streams` sub-batches on streams of the model's own: the kernel
         # boundaries, partial last rounds and store-bound epilogues of one sub-batch's launches fill with the other's
-        # work (same-box A/B at B = 32, 518 pixels: 2 streams +4.6 %, 3 streams +2.2 %, 4 streams -9 %).  Per-image
+        # work (same-box A/B at B = 32, 518 pixels: 2 streams +2 %: each half's GEMMs run 12 % slower than the whole
+        # batch's, the LayerNorm / focal / tail time hides).  Per-image
         # results do not depend on batch mates, so the outputs are bit-identical to a single-stream run.
         self.num_streams = max(1, int(config.get("streams", os.environ.get("COGAIM_STREAMS", "2"))))
         self._side_streams = None
