@@ -33,8 +33,8 @@ SIGNATURES = {
     "cogaim_gemm_batched_f32": [P, P, P, I, I, I, I, I, I, LL, LL, LL, I, I, P],
     "cogaim_focal_colsum_rows": [],
     "cogaim_focal_softmax_stats_colsum": [P, I, LL, P, P, P, I, I, P],
-    "cogaim_focal_attention_vector": [P, P, P, P, P, P, F, I, I, I, P],
-    "cogaim_focal_var_flag": [P, I, I, P, I, P],
+    "cogaim_focal_attention_candidates": [P, I, P, P, I, LL, P, P, P, P, I, I, P],
+    "cogaim_focal_attention_vector": [P, P, I, P, P, P, F, I, I, P, I, P],
     "cogaim_focal_weighted_colsum": [P, I, LL, P, P, P, P, I, I, P],
     "cogaim_focal_reduce_u": [P, P, P, I, I, I, P],
     "cogaim_focal_rowstats_parts": [I],

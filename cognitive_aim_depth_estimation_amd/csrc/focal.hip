@@ -282,35 +282,84 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   out[(size_t)b * N + c] = s0 + s1;
 }
 
-// per image: a = renorm(clamp(renorm(colmean + centre_bias)));  model.py:234-282
-__global__ __launch_bounds__(256) void focal_attention_vector_kernel(const float* colsum,
-                                                                     const float* __restrict__ cbias,
-                                                                     float* a, double* __restrict__ stats,
+// Sum of six doubles over a 256-thread block; result valid in every thread.  `redd` is 24 doubles of LDS.
+__device__ __forceinline__ void block_sum6_d(double (&v)[6], double* redd) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v[k] = wave_sum_d(v[k]);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) redd[(threadIdx.x >> 6) * 6 + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v[k] = redd[k] + redd[6 + k] + redd[12 + k] + redd[18 + k];
+}
+
+// The three deterministic summaries of the attention matrix the reference can end up using (model.py:234-249), per
+// image: cand[0] = column mean + centre bias, cand[1] = diagonal of P + bias, cand[2] = row maximum of P + bias, and
+// {sum, sum of squares} of each in fp64.  cand[0] arrives holding the column SUMS.  P = exp2(S - rmax) * rinv, so
+// its row maximum is rinv itself.  Without a score matrix in memory (S == NULL) cand[1] repeats cand[0].
+__global__ __launch_bounds__(256) void focal_attention_candidates_kernel(const float* __restrict__ cbias,
+                                                                         const float* __restrict__ S, int ldS,
+                                                                         long long strideS, const float* __restrict__ rmax,
+                                                                         const float* __restrict__ rinv, float* cand,
+                                                                         double* __restrict__ stats, int B, int N) {
+  __shared__ double redd[24];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const size_t plane = (size_t)B * N, row = (size_t)b * N;
+  const float invN = 1.0f / (float)N;
+  double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int c = tid; c < N; c += 256) {
+    const float bias = cbias[c], inv = rinv[row + c];
+    const float a0 = cand[row + c] * invN + bias;
+    const float a1 = S ? __builtin_amdgcn_exp2f(S[b * strideS + (size_t)c * ldS + c] - rmax[row + c]) * inv + bias : a0;
+    const float a2 = inv + bias;
+    cand[row + c] = a0; cand[plane + row + c] = a1; cand[2 * plane + row + c] = a2;
+    acc[0] += a0; acc[1] += (double)a0 * a0;
+    acc[2] += a1; acc[3] += (double)a1 * a1;
+    acc[4] += a2; acc[5] += (double)a2 * a2;
+  }
+  block_sum6_d(acc, redd);
+  if (tid < 6) stats[b * 6 + tid] = acc[tid];
+}
+
+// model.py:242-282 per image.  The cascade `if patch_attention.var() < 1e-6` (unbiased variance over the WHOLE batch)
+// picks column mean, else diagonal, else row maximum; if that is degenerate too the reference draws noise (:252-257),
+// which is not reproduced: flags[slot] = 1.  Then a = renorm(clamp(renorm(choice))) and the next iteration's token
+// scale (:426).  Every workgroup evaluates the cascade from all images' statistics.
+__global__ __launch_bounds__(256) void focal_attention_vector_kernel(const float* __restrict__ cand,
+                                                                     const double* __restrict__ stats, int have_diag,
+                                                                     float* __restrict__ a,
                                                                      const float* __restrict__ scale_in,
                                                                      float* __restrict__ scale_out, float focus_strength,
-                                                                     int N) {
+                                                                     int B, int N, int* __restrict__ flags, int slot) {
   __shared__ float red[4];
-  __shared__ double redd[8];
+  __shared__ double redd[24];
   const int b = blockIdx.x, tid = threadIdx.x;
+  double tot[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = tid; i < B; i += 256) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) tot[k] += stats[i * 6 + k];
+  }
+  block_sum6_d(tot, redd);
+  const double n = (double)B * N;
+  int sel = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double var = (tot[2 * k + 1] - tot[2 * k] * tot[2 * k] / n) / (n - 1.0);      // NaN for a single element: no fallback
+    if (sel == k && var < 1e-6) sel = k + 1;
+  }
+  if (!have_diag && sel >= 1) sel = 3;          // the diagonal would be needed and is not available
+  if (b == 0 && tid == 0) flags[slot] = (sel == 3) ? 1 : 0;
+  const float* src = cand + (size_t)(sel < 2 ? sel : 2) * B * N + (size_t)b * N;
   float* ab = a + (size_t)b * N;
-  float s1 = 0.f; double d1 = 0.0, d2 = 0.0;
-  const float invN = 1.0f / (float)N;
-  for (int c = tid; c < N; c += 256) {
-    const float pa = colsum[(size_t)b * N + c] * invN + cbias[c];
-    ab[c] = pa; s1 += pa; d1 += pa; d2 += (double)pa * pa;
-  }
-  const float t1 = block_sum_256(s1, red);
-  d1 = wave_sum_d(d1); d2 = wave_sum_d(d2);
-  if ((tid & 63) == 0) { redd[tid >> 6] = d1; redd[4 + (tid >> 6)] = d2; }
-  __syncthreads();
-  if (tid == 0) {
-    stats[2 * b] = redd[0] + redd[1] + redd[2] + redd[3];
-    stats[2 * b + 1] = redd[4] + redd[5] + redd[6] + redd[7];
-  }
-  const float d = t1 + 1e-8f;
+  float s1 = 0.f;
+  for (int c = tid; c < N; c += 256) s1 += src[c];
+  const float d = block_sum_256(s1, red) + 1e-8f;
   float s2 = 0.f;
   for (int c = tid; c < N; c += 256) {
-    const float v = fmaxf(ab[c] / d, 1e-8f);
+    const float v = fmaxf(src[c] / d, 1e-8f);
     ab[c] = v; s2 += v;
   }
   const float t2 = block_sum_256(s2, red) + 1e-8f;
@@ -319,16 +368,6 @@ __global__ __launch_bounds__(256) void focal_attention_vector_kernel(const float
     ab[c] = v;
     if (scale_out) scale_out[(size_t)b * N + c] = (scale_in ? scale_in[(size_t)b * N + c] : 1.0f) * (1.0f + focus_strength * v);
   }
-}
-
-// whole-batch unbiased variance of (colmean + bias) < 1e-6  ->  flags[slot] = 1   (model.py:242)
-__global__ void focal_var_flag_kernel(const double* __restrict__ stats, int B, int N, int* __restrict__ flags, int slot) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < B; ++b) { s += stats[2 * b]; q += stats[2 * b + 1]; }
-  const double n = (double)B * N;
-  const double var = (q - s * s / n) / (n - 1.0);
-  flags[slot] = (var < 1e-6) ? 1 : 0;
 }
 
 // usum[b] = sum_c u[b][c]
@@ -465,25 +504,31 @@ int cogaim_focal_weighted_colsum(const float* S, int ldS, long long strideS, con
   return COGAIM_LAUNCH_CHECK();
 }
 
-// a[b][:] from column-sum partials; stats[b] = {sum, sum of squares} of (colmean + bias) in fp64;
-// scale_out = scale_in * (1 + focus_strength * a) when scale_out != NULL (scale_in NULL = ones).
-int cogaim_focal_attention_vector(const float* part, const float* center_bias, float* a, double* stats,
-                                  const float* scale_in, float* scale_out, float focus_strength, int B, int N,
-                                  int nblk, void* stream) {
-  if (B <= 0 || N <= 0) return COGAIM_EINVAL;
+// cand [3][B][N], stats fp64 [B][6]: the three candidate summaries of model.py:234-249 and their per-image {sum, sum
+// of squares}.  part [B, nblk, N] column-sum partials (nblk <= 0 = ceil(N / cogaim_focal_colsum_rows())); S may be
+// NULL when no score matrix is kept in memory (the diagonal candidate then repeats the column mean).
+int cogaim_focal_attention_candidates(const float* part, int nblk, const float* center_bias, const float* S, int ldS,
+                                      long long strideS, const float* rmax, const float* rinv, float* cand, double* stats,
+                                      int B, int N, void* stream) {
+  if (B <= 0 || N <= 0 || (S && ldS < N)) return COGAIM_EINVAL;
   if (nblk <= 0) nblk = (N + CS_ROWS - 1) / CS_ROWS;
-  // the reduced column sums are staged in `a` itself (the kernel reads a[b][c] before overwriting it); the reduction
+  // the reduced column sums are staged in cand[0] (the kernel reads cand[0][b][c] before overwriting it); the reduction
   // stays a launch of its own: one thread per column over a wide grid takes 8 us, folded into the one-workgroup-
   // per-image kernel behind it 40 us (43 dependent-latency loads per column on 16 CUs)
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, part, nblk, a, N);
-  hipLaunchKernelGGL(focal_attention_vector_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)a,
-                     center_bias, a, stats, scale_in, scale_out, focus_strength, N);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, part, nblk, cand, N);
+  hipLaunchKernelGGL(focal_attention_candidates_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, center_bias, S, ldS,
+                     strideS, rmax, rinv, cand, stats, B, N);
   return COGAIM_LAUNCH_CHECK();
 }
 
-// flags[slot] = (unbiased variance over the whole [B,N] batch < 1e-6)
-int cogaim_focal_var_flag(const double* stats, int B, int N, int* flags, int slot, void* stream) {
-  hipLaunchKernelGGL(focal_var_flag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, B, N, flags, slot);
+// a[b][:] from the candidates by the reference's variance cascade; flags[slot] = 1 when even the last deterministic
+// candidate is degenerate (or the diagonal is needed and have_diag is 0), else 0;
+// scale_out = scale_in * (1 + focus_strength * a) when scale_out != NULL (scale_in NULL = ones).
+int cogaim_focal_attention_vector(const float* cand, const double* stats, int have_diag, float* a, const float* scale_in,
+                                  float* scale_out, float focus_strength, int B, int N, int* flags, int slot, void* stream) {
+  if (B <= 0 || N <= 0 || !flags || slot < 0) return COGAIM_EINVAL;
+  hipLaunchKernelGGL(focal_attention_vector_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, cand, stats, have_diag, a,
+                     scale_in, scale_out, focus_strength, B, N, flags, slot);
   return COGAIM_LAUNCH_CHECK();
 }
 

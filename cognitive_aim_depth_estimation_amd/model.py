@@ -443,7 +443,8 @@ class CognitiveAimModel(nn.Module):
             "gemm_ws": torch.empty(call("cogaim_gemm_workspace_bytes"), device=dev, dtype=torch.uint8),
             "rmax": torch.empty(B, N, **f32), "rinv": torch.empty(B, N, **f32),
             "part": torch.empty(B * nblk * N, **f32), "attn": torch.empty(B, N, **f32),
-            "scale": torch.empty(2, B, N, **f32), "stats": torch.empty(B, 2, device=dev, dtype=torch.float64),
+            "scale": torch.empty(2, B, N, **f32), "stats": torch.empty(B, 6, device=dev, dtype=torch.float64),
+            "cand": torch.empty(3, B, N, **f32),
             "flags": torch.zeros(_FLAG_WORDS, device=dev, dtype=torch.int32),
             # host snapshots of the flag words, one per forward, examined when their copy has landed
             "flag_ring": [{"host": torch.zeros(_FLAG_WORDS, dtype=torch.int32).pin_memory(), "event": torch.cuda.Event(),
@@ -532,9 +533,11 @@ class CognitiveAimModel(nn.Module):
             else:
                 call("cogaim_gemm_batched_f32", qk, h, S, N, N, D, D, D, ldS, N * D, N * D, N * ldS, B, dt, st)
                 call("cogaim_focal_softmax_stats_colsum", S, ldS, N * ldS, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["part"]), B, N, st)
-            call("cogaim_focal_attention_vector", ptr(ws["part"]), ptr(cb), ptr(ws["attn"]), ptr(ws["stats"]),
-                 s_in, s_out, self.focus_strength, B, N, ws["nblk"], st)
-            call("cogaim_focal_var_flag", ptr(ws["stats"]), B, N, ptr(ws["flags"]), i, st)
+            # :234-282: column mean / diagonal / row maximum (+ centre bias) and the reference's variance cascade
+            call("cogaim_focal_attention_candidates", ptr(ws["part"]), ws["nblk"], ptr(cb), None if ws["tiled"] else S, ldS,
+                 N * ldS, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["cand"]), ptr(ws["stats"]), B, N, st)
+            call("cogaim_focal_attention_vector", ptr(ws["cand"]), ptr(ws["stats"]), 0 if ws["tiled"] else 1, ptr(ws["attn"]),
+                 s_in, s_out, self.focus_strength, B, N, ptr(ws["flags"]), i, st)
             if ws["tiled"]:
                 call("cogaim_focal_scores_colsum", qk, h, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["attn"]), ptr(ws["part"]),
                      N, D, D, N * D, B, dt, st)
@@ -556,10 +559,11 @@ class CognitiveAimModel(nn.Module):
             ws["cat"][:, col:col + 64].copy_(ws["feats"])
 
     def _check_fallback_flags(self, ws):
-        """The reference switches to other attention summaries when the whole-batch variance
-        of (column mean + centre bias) is below 1e-6 (src/model.py:242-257).  The predicate is
-        evaluated on device; it cannot fire for any grid larger than 1x1 (the centre bias alone
-        has variance far above the threshold), so a set flag is reported, not emulated.
+        """The reference switches to other attention summaries when the whole-batch variance of (column mean +
+        centre bias) is below 1e-6: the diagonal, then the row maximum, then token norms plus noise
+        (src/model.py:242-257).  The first two steps of that cascade are evaluated on the device inside the forward
+        (they can only trigger on grids of 2, 3 or 2 x 2 patches: the constant the sum would have to equal must reach
+        the bias at the centre, 0.3); the noise step is not reproduced and is reported through the flag words.
 
         Every forward copies the flag words to one of a few pinned host snapshots asynchronously; a snapshot is
         examined by a later call on this workspace once its copy has landed, or by ``synchronize()``: the forward
@@ -600,8 +604,9 @@ class CognitiveAimModel(nn.Module):
                                     "stored as inf: results of that call are not valid.  Build the model with "
                                     "compute_dtype='bf16' (same speed, fp32 exponent range) for these weights")
             elif ws["N"] > 1 and bool(host[: self.num_iterations].any()):
-                err = RuntimeError("focal attention variance fell below 1e-6 in an earlier forward: the "
-                                   "reference's degenerate-attention fallbacks (src/model.py:242-257) are not built")
+                err = RuntimeError("in an earlier forward the focal attention summaries (column mean, diagonal, row "
+                                   "maximum: src/model.py:234-249) were all degenerate (whole-batch variance < 1e-6); "
+                                   "the reference then draws noise (:252-257), which is not reproduced")
             if err is not None:
                 # reported once: younger snapshots were taken before the device words were cleared just above
                 for other in ring:

@@ -118,11 +118,21 @@ int cogaim_focal_colsum_rows(void);
 int cogaim_focal_softmax_stats_colsum(const float* S, int ldS, long long strideS, float* rmax, float* rinv, float* part,
                                       int B, int N, void* stream);
 
-/* :239-282 centre bias, L1 normalise, clamp, renormalise -> a[B,N]; also :426 next-iteration token scale.
- * part [B, nblk, N] column-sum partials; nblk <= 0 = ceil(N / cogaim_focal_colsum_rows()). */
-int cogaim_focal_attention_vector(const float* part, const float* center_bias, float* a, double* stats,
-                                  const float* scale_in, float* scale_out, float focus_strength, int B, int N,
-                                  int nblk, void* stream);
+/* :234-249 the three deterministic summaries of the attention matrix the reference chooses between, each with the
+ * centre bias added: cand[0] = column mean (:234-239), cand[1] = diagonal (:243-244), cand[2] = row maximum
+ * (:248-249); cand fp32 [3][B][N], stats fp64 [B][6] = per-image {sum, sum of squares} of each.
+ * part [B, nblk, N] column-sum partials; nblk <= 0 = ceil(N / cogaim_focal_colsum_rows()).  S (scores, log2 domain,
+ * leading dimension ldS, strideS between images) may be NULL when no score matrix is kept: cand[1] repeats cand[0]. */
+int cogaim_focal_attention_candidates(const float* part, int nblk, const float* center_bias, const float* S, int ldS,
+                                      long long strideS, const float* rmax, const float* rinv, float* cand, double* stats,
+                                      int B, int N, void* stream);
+
+/* :242-282 the cascade `if patch_attention.var() < 1e-6` (unbiased variance over the whole batch) over the candidates,
+ * then L1 normalise, clamp, renormalise -> a[B,N]; also :426 next-iteration token scale.  flags[slot] = 1 when the
+ * last deterministic candidate is degenerate as well (the reference then draws noise, :252-257: not reproduced) or
+ * the diagonal is needed and have_diag is 0; else 0. */
+int cogaim_focal_attention_vector(const float* cand, const double* stats, int have_diag, float* a, const float* scale_in,
+                                  float* scale_out, float focus_strength, int B, int N, int* flags, int slot, void* stream);
 
 /* The same :197-204, :234 for large grids, with no score matrix in memory (N x N fp32 is 120 MB per image at
  * 1036 pixels): S = Y X^T is formed tile by tile three times and reduced in registers --
@@ -140,9 +150,6 @@ int cogaim_focal_rowstats_combine(const float* pmax, const float* psum, int part
                                   void* stream);
 int cogaim_focal_scores_colsum(const void* Y, const void* X, const float* rmax, const float* rinv, const float* roww,
                                float* part, int N, int D, int ld, long long stride, int batch, int dtype, void* stream);
-
-/* :242 `patch_attention.var() < 1e-6` over the whole batch, evaluated on device into flags[slot]. */
-int cogaim_focal_var_flag(const double* stats, int B, int N, int* flags, int slot, void* stream);
 
 /* :204,:308  sum_n a_n (P V)_n = (a^T P) V:  part[b][blk][c] = sum_{n in blk} roww[b][n] P[b][n][c]. */
 int cogaim_focal_weighted_colsum(const float* S, int ldS, long long strideS, const float* rmax, const float* rinv,

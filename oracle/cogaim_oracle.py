@@ -185,20 +185,24 @@ def focal_stream(sd: SD, prefix: str, x: Tensor, num_heads: int = 8,
     cb = center_bias(N)
     colmean = p.mean(dim=1)                                      # :234
     pa = colmean + cb.unsqueeze(0)                               # :239
+    branch = 0                                                   # which summary ends up in use (0 = column mean)
     if pa.var() < 1e-6:                                          # :242
         pa = torch.diagonal(p, dim1=-2, dim2=-1) + cb.unsqueeze(0)
+        branch = 1
     if pa.var() < 1e-6:                                          # :247
         pa = p.max(dim=-1)[0] + cb.unsqueeze(0)
+        branch = 2
     if pa.var() < 1e-6:                                          # :252
         norms = torch.norm(xt, dim=-1)
         pa = norms + torch.randn_like(norms) * 0.1 * norms.std()
+        branch = 3
     pa = pa / (pa.sum(dim=-1, keepdim=True) + 1e-8)              # :261
     a = torch.clamp(pa, min=1e-8)                                # :281
     a = a / (a.sum(dim=-1, keepdim=True) + 1e-8)                 # :282
     w = torch.sum(o * a.unsqueeze(-1), dim=1)                    # :308
     f = _lin(sd, prefix + "projection.3", F.relu(_lin(sd, prefix + "projection.0", w)))  # :311
     if return_parts:
-        return f, a, {"colmean": colmean, "weighted": w}
+        return f, a, {"colmean": colmean, "weighted": w, "branch": branch}
     return f, a
 
 

@@ -446,6 +446,93 @@ def g11_large_backbone(ref):
     save("g11_large_backbone", **arrays)
 
 
+def g12_degenerate_attention(ref):
+    """Inputs on which the REAL FocalStream takes its degenerate-attention fallbacks (src/model.py:242-249) on grids of
+    more than one patch: the tokens are chosen so that (column mean of the attention + centre bias) is the same number
+    for every patch of every image, i.e. its whole-batch variance is 0.  Only grids of 2, 3 and 2 x 2 patches admit
+    that (the constant must reach the bias at the centre, 0.3).  Case 'rows_equal': every attention row is the same,
+    so the diagonal (first fallback) is degenerate too and the row maximum (second fallback) decides; 'rows_differ':
+    rows differ, the diagonal decides.  The third fallback (:252-257) draws noise and is not pinned."""
+    arrays = {}
+    torch.manual_seed(12)
+    taken = []
+    real_var = torch.Tensor.var
+
+    def spy_var(self, *a, **k):
+        v = real_var(self, *a, **k)
+        taken.append(float(v))
+        return v
+
+    for tag, n, differ in (("rows_equal4", 4, False), ("rows_differ4", 4, True), ("rows_differ3", 3, True),
+                           ("rows_equal2", 2, False)):
+        fs = ref.FocalStream(64, curiosity_guided=False).eval()
+        B = 2
+        captured = {}
+        hook = fs.query_proj.register_forward_pre_hook(
+            lambda mod, inp: captured.__setitem__("xt", inp[0].detach().clone()))
+        with torch.no_grad(), quiet():
+            fs(torch.zeros(1, n, 64))
+        pe = captured["xt"][0].double()                                   # the position table the stream adds
+        # centre bias exactly as the stream builds it: run it on uniform attention and subtract
+        with torch.no_grad():
+            fs.query_proj.weight.zero_(); fs.query_proj.bias.zero_()
+            fs.key_proj.weight.zero_(); fs.key_proj.bias.zero_()
+            with quiet():
+                _, a_uniform = fs(torch.zeros(1, n, 64))
+        # with zero scores P = 1/n; a = renorm(1/n + bias) -> bias up to the normalisation: recover it from ratios
+        g = int(n ** 0.5)
+        if g * g == n:
+            yy, xx = torch.meshgrid(torch.arange(g), torch.arange(g), indexing="ij")
+            d = torch.sqrt((xx - g // 2).float() ** 2 + (yy - g // 2).float() ** 2)
+            bias = (torch.exp(-d ** 2 / (2 * (g / 6) ** 2)).flatten() * 0.3).double()
+        else:
+            d = torch.abs(torch.arange(n, dtype=torch.float) - n // 2)
+            bias = (torch.exp(-d ** 2 / (2 * (n / 12) ** 2)) * 0.3).double()
+        chk = (1.0 / n + bias) / (1.0 / n + bias).sum()
+        assert torch.allclose(a_uniform[0].double(), chk, atol=1e-6), (a_uniform, chk)
+        C = (1.0 + bias.sum()) / n
+        t = C - bias                                                      # the column means that make the sum constant
+        assert (t > 0).all(), t
+        s_gain = 4.0
+        with torch.no_grad():
+            fs.query_proj.bias[0] = s_gain                                # q_n = [s, xt_n[1], 0, ...]
+            fs.query_proj.weight[1, 1] = 1.0
+            fs.key_proj.weight[0, 0] = 1.0                                # k_c = [xt_c[0], xt_c[2], 0, ...]
+            fs.key_proj.weight[1, 2] = 1.0
+        xt = torch.randn(B, n, 64).double() * 0.5
+        if not differ:
+            xt[:, :, 1] = 0.0
+        scale = (64 // 8) ** 0.5
+        f = torch.log(t).repeat(B, 1)                                     # per-column offsets, solved per image
+        for _ in range(200):
+            S = (s_gain * f.unsqueeze(1) * scale / s_gain + xt[:, :, 1].unsqueeze(2) * xt[:, :, 2].unsqueeze(1)) / scale
+            colmean = torch.softmax(S, dim=-1).mean(dim=1)
+            f = f + torch.log(t.unsqueeze(0) / colmean)
+        assert float((colmean - t).abs().max()) < 1e-12
+        xt[:, :, 0] = f * scale / s_gain
+        x = (xt - pe.unsqueeze(0)).float()
+        taken.clear()
+        torch.Tensor.var = spy_var
+        try:
+            with torch.no_grad(), quiet():
+                feat, att = fs(x)
+        finally:
+            torch.Tensor.var = real_var
+        small = [v < 1e-6 for v in taken]
+        branch = 0
+        for v in small:
+            if not v:
+                break
+            branch += 1
+        assert branch in (1, 2), (tag, taken)                             # 1: diagonal decided, 2: row maximum decided
+        assert branch == (1 if differ else 2), (tag, taken)
+        arrays.update(npd(fs.state_dict(), f"{tag}:w:"))
+        arrays[f"{tag}:x"], arrays[f"{tag}:f"], arrays[f"{tag}:a"] = x.numpy(), feat.numpy(), att.numpy()
+        arrays[f"{tag}:branch"] = branch
+        arrays[f"{tag}:variances"] = np.array(taken[:3] + [0.0] * (3 - len(taken[:3])))
+    save("g12_degenerate_attention", **arrays)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
@@ -459,6 +546,7 @@ def main():
     g9_single_patch(ref)
     g10_bare_focal_stream(ref)
     g11_large_backbone(ref)
+    g12_degenerate_attention(ref)
 
 
 if __name__ == "__main__":

@@ -520,3 +520,87 @@ def test_large_backbone_full_resolution_vs_oracle(dtype):
     e = dict(depth=rel_err(d, od), conf=rel_err(c, oc), attn=rel_err(a, oa))
     report(test="large_full_resolution", dtype=dtype, **e)
     assert e["depth"] <= 1e-3 and e["conf"] <= 1e-3 and e["attn"] <= TOL[dtype]["attn"], e
+
+
+def _degenerate_focal_case(grid, differ, seed):
+    """A bare FocalStream (768 columns) and tokens for which (column mean of the attention + centre bias) is the same
+    number for every patch of every image -- the construction of tests/golden/g12_degenerate_attention.npz, which pins
+    the oracle's handling of it to the real reference."""
+    from cognitive_aim_depth_estimation_amd import create_model
+    from oracle.weights import reference_state_spec, synth_state_dict
+    mods = ["ambient_stream", "focal_stream", "exif_prior_database"]
+    model = create_model({"cognitive_modules": mods, "compute_dtype": "fp16",
+                          "backbone_config": {"num_hidden_layers": 1, "image_size": 56}}, {"num_cameras": 71}, device="cuda")
+    sd = synth_state_dict(reference_state_spec(layers=1, native_grid=4, modules=tuple(mods)), seed=seed)
+    D, (gh, gw), B, gain = 768, grid, 2, 4.0
+    N = gh * gw
+    wq, bq, wk = torch.zeros(D, D), torch.zeros(D), torch.zeros(D, D)
+    bq[0], wq[1, 1], wk[0, 0], wk[1, 2] = gain, 1.0, 1.0, 1.0          # q_n = [gain, xt_n[1], 0...], k_c = [xt_c[0], xt_c[2], 0...]
+    sd.update({"focal_stream.query_proj.weight": wq, "focal_stream.query_proj.bias": bq,
+               "focal_stream.key_proj.weight": wk, "focal_stream.key_proj.bias": torch.zeros(D)})
+    model.load_state_dict(sd, strict=True)
+    pe, bias = O.pe2d_table(N, D).double(), O.center_bias(N).double()
+    t = (1.0 + bias.sum()) / N - bias                                  # column means that make the sum constant
+    assert (t > 0).all()
+    g = torch.Generator().manual_seed(seed)
+    xt = torch.randn(B, N, D, generator=g).double() * 0.5
+    if differ:
+        xt[:, :, 1:3] *= 5.0                                           # attention rows that differ visibly
+    else:
+        xt[:, :, 1] = 0.0                                              # every attention row the same
+    scale = (D // 8) ** 0.5
+    f = torch.log(t).repeat(B, 1)
+    for _ in range(2000):
+        S = f.unsqueeze(1) + xt[:, :, 1].unsqueeze(2) * xt[:, :, 2].unsqueeze(1) / scale
+        f = f + torch.log(t.unsqueeze(0) / torch.softmax(S, dim=-1).mean(dim=1))
+    S = f.unsqueeze(1) + xt[:, :, 1].unsqueeze(2) * xt[:, :, 2].unsqueeze(1) / scale
+    assert float((torch.softmax(S, dim=-1).mean(dim=1) - t).abs().max()) < 1e-9
+    f = f - f.mean(dim=1, keepdim=True)                                # softmax ignores the shift; small 16-bit operands
+    xt[:, :, 0] = f * scale / gain
+    x = (xt - pe.unsqueeze(0)).float()
+    return model, sd, x, (gh, gw)
+
+
+@pytest.mark.parametrize("grid,differ", [((2, 2), False), ((2, 2), True), ((1, 3), True), ((1, 2), False)])
+def test_degenerate_attention_fallbacks(grid, differ):
+    """The reference's first two fallbacks (diagonal of the attention matrix, then its row maxima: src/model.py:242-249)
+    evaluated on the device: inputs whose column-mean summary has zero whole-batch variance, against the oracle (which
+    g12 pins to the real reference on the same construction)."""
+    model, sd, x, (gh, gw) = _degenerate_focal_case(grid, differ, seed=31 + grid[0] * grid[1])
+    B, N, D = x.shape
+    f_ref, a_ref, parts = O.focal_stream(sd, "focal_stream.", x, return_parts=True)
+    assert parts["branch"] == (1 if differ else 2)                     # the oracle did take the fallback under test
+    model._pack()
+    ws = model._workspace(B, gh, gw)
+    tokens = torch.cat([torch.zeros(B, 1, D), x], dim=1)
+    ws["tokens"].copy_(tokens.view(B * (N + 1), D))
+    ws["cat"].zero_()
+    model._focal(B, ws)
+    model._focal_fused_into(ws, B, 64)
+    torch.cuda.synchronize()
+    assert int(ws["flags"][0]) == 0
+    ea = rel_err(ws["attn"], a_ref)
+    ef = float((ws["cat"][:, 64:128].cpu() - f_ref).abs().max() / f_ref.abs().max())
+    report(test="degenerate_fallback", grid=list(grid), branch=parts["branch"], attn=ea, feat=ef)
+    assert ea <= 2e-3 and ef <= 2e-3, (ea, ef)                         # measured 4e-5 ... 2e-4
+    uniform = torch.full_like(a_ref, 1.0 / N)                          # what the flat column-mean summary would give
+    assert float((a_ref - uniform).abs().max()) > 0.01                 # ... far outside that tolerance
+
+
+def test_degenerate_attention_without_scores_in_memory_is_reported():
+    """With the score tiles reduced in registers (the large-grid form) the diagonal is not available: a degenerate
+    column-mean summary is then reported by synchronize() instead of being followed."""
+    import pytest as _pt
+    model, sd, x, (gh, gw) = _degenerate_focal_case((2, 2), True, seed=77)
+    model.scores_in_memory_max_patches = 0
+    B, N, D = x.shape
+    model._pack()
+    ws = model._workspace(B, gh, gw)
+    assert ws["tiled"]
+    ws["tokens"].copy_(torch.cat([torch.zeros(B, 1, D), x], dim=1).view(B * (N + 1), D))
+    ws["cat"].zero_()
+    model._focal(B, ws)
+    model._check_fallback_flags(ws)
+    with _pt.raises(RuntimeError, match="degenerate"):
+        model.synchronize()
+    model.synchronize()

@@ -218,3 +218,15 @@ def test_large_backbone_vs_reference():
         assert np.allclose(got.numpy(), z[key], rtol=2e-4, atol=1e-7), key
     # the 768-wide curiosity module raises on 1024 columns before drawing anything; the reference catches it
     assert int(z["curiosity_failures56"]) == 2 and bool(z["history_untouched"])
+
+
+@pytest.mark.parametrize("tag", ["rows_equal4", "rows_differ4", "rows_differ3", "rows_equal2"])
+def test_degenerate_attention_fallbacks_vs_reference(tag):
+    """Inputs on which the real FocalStream takes its first (diagonal) or second (row maximum) fallback
+    (reference src/model.py:242-249) on grids of 2, 3 and 2 x 2 patches: tests/golden/g12_degenerate_attention.npz."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g12_degenerate_attention.npz"))
+    sd = {k[len(tag) + 3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + ":w:")}
+    f, a = O.focal_stream(sd, "", torch.from_numpy(z[tag + ":x"]))
+    assert np.allclose(a.numpy(), z[tag + ":a"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(f.numpy(), z[tag + ":f"], rtol=1e-4, atol=1e-6)
+    assert int(z[tag + ":branch"]) == (1 if "differ" in tag else 2)
