@@ -19,6 +19,7 @@ P, I, F, LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 SIGNATURES = {
     "cogaim_version": [],
     "cogaim_preprocess_rgb8": [P, I, I, LL, I, P, P, I, P, P, I, P, P, P, I, I, P],
+    "cogaim_preprocess_rgb8_batch": [P, I, I, P, I, I, P],
     "cogaim_gemm_workspace_bytes": [],
     "cogaim_set_gemm_algo": [I],
     "cogaim_im2col": [P, P, I, I, I, I, I, I, P],

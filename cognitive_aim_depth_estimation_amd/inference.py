@@ -131,8 +131,9 @@ class DevicePreprocessor:
 
 def _preprocess_batch(self, arrays, out: torch.Tensor, pool=None) -> torch.Tensor:
     """Several decoded images in one go: their bytes are packed into a pinned staging buffer (two, used in turn),
-    cross to the device in ONE asynchronous copy on the current stream, and the resize / normalise kernel runs once
-    per image on its slice.  arrays: uint8 [h, w, 3] (packed RGB) or [h, w, 4] (RGBX, fourth byte ignored) each, sizes
+    cross to the device in ONE asynchronous copy on the current stream together with one 88-byte record per image
+    (addresses, sizes, resampling tables), and the resize / normalise passes run as two launches over the whole batch
+    (cogaim_preprocess_rgb8_batch).  arrays: uint8 [h, w, 3] (packed RGB) or [h, w, 4] (RGBX, fourth byte ignored) each, sizes
     may differ; out: fp32 [len(arrays), 3, H, W].
     pool: an executor whose threads do the packing copies side by side (the caller then waits once, not per image)."""
     from ._lib import call, ptr, stream_ptr
@@ -148,6 +149,8 @@ def _preprocess_batch(self, arrays, out: torch.Tensor, pool=None) -> torch.Tenso
             raise ValueError(f"expected uint8 RGB / RGBX arrays, got {a.dtype} {a.shape}")
         offs.append(total)
         total += (a.size + 255) // 256 * 256
+    rec_off = total                                # the per-image records ride behind the pixels in the same copy
+    total += (len(arrays) * _ITEM.itemsize + 255) // 256 * 256
     st = getattr(self, "_stage", None)
     if st is None:
         st = self._stage = {"turn": 0, "pinned": [None, None], "event": [None, None], "dev": None}
@@ -160,6 +163,20 @@ def _preprocess_batch(self, arrays, out: torch.Tensor, pool=None) -> torch.Tenso
     if st["dev"] is None or st["dev"].numel() < total:
         st["dev"] = torch.empty(max(total, 1 << 20), dtype=torch.uint8, device=self.device)
     host = st["pinned"][t].numpy()
+    tmp_offs, need = [], 0
+    for a in arrays:
+        tmp_offs.append(need)
+        need += (int(a.shape[0]) * W * 3 + 255) // 256 * 256
+    if self._tmp is None or self._tmp.numel() < need:
+        self._tmp = torch.empty(need, dtype=torch.uint8, device=self.device)
+    base, tmp_base = st["dev"].data_ptr(), self._tmp.data_ptr()
+    rec = host[rec_off: rec_off + len(arrays) * _ITEM.itemsize].view(_ITEM)
+    for j, (a, o) in enumerate(zip(arrays, offs)):
+        h, w, px = int(a.shape[0]), int(a.shape[1]), int(a.shape[2])
+        xb, xc, xk = self._axis_tables(w, W)
+        yb, yc, yk = self._axis_tables(h, H)
+        rec[j] = (base + o, w * px, ptr(xb), ptr(xc), ptr(yb), ptr(yc), tmp_base + tmp_offs[j], out[j].data_ptr(),
+                  h, w, px, xk, yk, 0)
     t_1 = time.perf_counter()
     if pool is None:
         for a, o in zip(arrays, offs):
@@ -172,17 +189,9 @@ def _preprocess_batch(self, arrays, out: torch.Tensor, pool=None) -> torch.Tenso
     ev.record()
     st["event"][t] = ev
     t_3 = time.perf_counter()
-    need = max((a.shape[0] for a in arrays), default=0) * W * 3
-    if self._tmp is None or self._tmp.numel() < need:
-        self._tmp = torch.empty(need, dtype=torch.uint8, device=self.device)
-    base = st["dev"].data_ptr()
-    for j, (a, o) in enumerate(zip(arrays, offs)):
-        h, w = int(a.shape[0]), int(a.shape[1])
-        xb, xc, xk = self._axis_tables(w, W)
-        yb, yc, yk = self._axis_tables(h, H)
-        px = int(a.shape[2])
-        call("cogaim_preprocess_rgb8", base + o, h, w, w * px, px, ptr(xb), ptr(xc), xk, ptr(yb), ptr(yc), yk,
-             ptr(self._tmp), ptr(self._lut), out[j].data_ptr(), H, W, stream_ptr())
+    if arrays:
+        call("cogaim_preprocess_rgb8_batch", base + rec_off, len(arrays), max(int(a.shape[0]) for a in arrays),
+             ptr(self._lut), H, W, stream_ptr())
     if tm is not None:
         t_4 = time.perf_counter()
         for k, v in (("stage_wait_s", t_1 - t_0), ("pack_s", t_2 - t_1), ("upload_issue_s", t_3 - t_2), ("launch_s", t_4 - t_3)):
@@ -190,6 +199,11 @@ def _preprocess_batch(self, arrays, out: torch.Tensor, pool=None) -> torch.Tenso
     return out
 
 
+# one image of cogaim_preprocess_rgb8_batch (88 bytes, the layout include/cogaim.h gives)
+_ITEM = np.dtype([("src", "<u8"), ("row_bytes", "<i8"), ("xbounds", "<u8"), ("xcoefs", "<u8"), ("ybounds", "<u8"),
+                  ("ycoefs", "<u8"), ("tmp", "<u8"), ("dst", "<u8"), ("h", "<i4"), ("w", "<i4"), ("px", "<i4"),
+                  ("xk", "<i4"), ("yk", "<i4"), ("pad", "<i4")])
+assert _ITEM.itemsize == 88
 DevicePreprocessor.batch = _preprocess_batch
 
 

@@ -44,6 +44,14 @@ int cogaim_preprocess_rgb8(const void* src, int src_h, int src_w, long long src_
                            const int* xcoefs, int xk, const int* ybounds, const int* ycoefs, int yk, void* tmp,
                            const float* lut, float* dst, int out_h, int out_w, void* stream);
 
+/* The same for a batch of n decoded images in two launches (the demo.py loop at demo.py:406-432 preprocesses file by
+ * file).  items: n records of 88 bytes in DEVICE memory, one per image:
+ *   { u64 src, i64 src_row_bytes, u64 xbounds, u64 xcoefs, u64 ybounds, u64 ycoefs, u64 tmp, u64 dst,
+ *     i32 src_h, i32 src_w, i32 src_pixel_bytes, i32 xk, i32 yk, i32 0 }
+ * with the meaning of the arguments of cogaim_preprocess_rgb8 (every image its own tmp); max_src_h = largest src_h. */
+int cogaim_preprocess_rgb8_batch(const void* items, int n, int max_src_h, const float* lut, int out_h, int out_w,
+                                 void* stream);
+
 /* The GEMM entry points take an optional `workspace` (device memory, `workspace_bytes` long;
  * NULL/0 allowed).  With at least cogaim_gemm_workspace_bytes() bytes they split the tiles of
  * a partial last round along K over the idle CUs (fp32 partials, summed in fixed order: results

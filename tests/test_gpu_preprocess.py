@@ -89,3 +89,17 @@ def test_batch_of_rgbx_views_equals_packed_rgb(tmp_path):
         assert arr.shape == (90, 120, 4) and not arr.flags.owndata
     arr2, _, _ = CognitiveAimInference._decode(None, p_pal)
     assert np.array_equal(arr2[:, :, :3], np.asarray(PIL.open(p_pal).convert("RGB")))
+
+
+def test_batched_launch_equals_per_image_launches():
+    """cogaim_preprocess_rgb8_batch (two launches for the whole chunk, records in device memory) against the
+    per-image entry point: bit-identical, sizes and pixel strides mixed."""
+    rng = np.random.default_rng(9)
+    pre = DevicePreprocessor((70, 56), "cuda")
+    arrays = [rng.integers(0, 256, size=(h, w, c), dtype=np.uint8)
+              for h, w, c in ((90, 120, 3), (33, 47, 4), (518, 518, 4), (64, 200, 3), (7, 9, 3))]
+    batch = pre.batch(arrays, torch.zeros(5, 3, 70, 56, device="cuda")).clone()
+    torch.cuda.synchronize()
+    for i, a in enumerate(arrays):
+        single = pre(np.ascontiguousarray(a[:, :, :3]))
+        assert torch.equal(batch[i], single), i
