@@ -58,7 +58,7 @@ def run(name):
     elif kind == "gelu":
         call("cogaim_gemm_bias_gelu_half", ptr(A), ptr(W), ptr(bias), ptr(out16), M, N, K, K, K, N, dt, *wsp, None, st)
     elif kind == "res":
-        call("cogaim_gemm_residual_f32", ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(x), M, N, K, K, K, N, dt, *wsp, None, st)
+        call("cogaim_gemm_residual_f32", ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(x), M, N, K, K, K, N, dt, *wsp, st)
 
 
 def check(name):
