@@ -37,3 +37,15 @@ def test_model_refuses_cpu():
                       "backbone_config": {"num_hidden_layers": 1, "image_size": 28}})
     with pytest.raises(RuntimeError, match="no CPU path"):
         m(torch.zeros(1, 3, 28, 28))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No fallback: with the shared library absent the binding raises and names the build command."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['COGAIM_LIB'] = %r\n"
+            "from cognitive_aim_depth_estimation_amd import _lib\n"
+            "try:\n    _lib.call('cogaim_version')\nexcept _lib.CogaimError as e:\n    print('RAISED', e)\n"
+            % (ROOT, str(tmp_path / "absent" / "libcogaim.so")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "RAISED" in out.stdout and "cognitive_aim_depth_estimation_amd.build" in out.stdout, out.stdout + out.stderr
