@@ -127,3 +127,32 @@ def test_instruction_sweep_through_the_harness(workdir, monkeypatch):
     assert rel_err(torch.tensor([[d]]), d_ref) <= 1e-3 and rel_err(torch.tensor([[c]]), c_ref) <= 1e-3
     d_def, _, _ = h.predict(paths[2])
     assert abs(d_def - d) > 1e-6                               # the EXIF values matter
+
+
+def test_mixed_image_modes_and_a_multi_block_image(workdir, tmp_path):
+    """Files that are not plain small RGB: grayscale, RGBA, palette, CMYK (all converted like the reference's
+    Image.open(...).convert('RGB'), demo.py:312) and an image too large for Pillow's single-block storage, where the
+    zero-copy hand-over is not available and the packed copy is used.  Results against the oracle on the host path."""
+    _, cfg, ckpt, sd = workdir
+    rng = np.random.default_rng(21)
+    files = []
+    for name, mode, shape in (("gray.png", "L", (80, 100)), ("rgba.png", "RGBA", (70, 90, 4)), ("cmyk.jpg", "CMYK", (60, 60, 4)),
+                              ("plain.png", "RGB", (50, 75, 3))):
+        p = str(tmp_path / name)
+        PIL.fromarray(rng.integers(0, 256, size=shape, dtype=np.uint8), mode).save(p)
+        files.append(p)
+    pal = str(tmp_path / "pal.png")
+    PIL.fromarray(rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8), "RGB").convert("P").save(pal)
+    big = str(tmp_path / "big.png")                                        # 2400 x 2400 x 4 bytes = 23 MB: several blocks
+    tile = rng.integers(0, 256, size=(40, 40, 3), dtype=np.uint8)
+    PIL.fromarray(np.tile(tile, (60, 60, 1)), "RGB").save(big, compress_level=1)
+    files += [pal, big]
+    arr, _, size = inf.CognitiveAimInference._decode(None, big)
+    assert size == (2400, 2400) and arr.shape[:2] == (2400, 2400)
+    h = inf.CognitiveAimInference(cfg, ckpt, device="cuda", batch_size=4, render=False)
+    res = h.predict_batch(files)
+    assert all(r[0] is not None for r in res), [r[2] for r in res if r[0] is None]
+    d_ref, c_ref, _ = _oracle(sd, files)
+    d = torch.tensor([[r[0]] for r in res])
+    c = torch.tensor([[r[1]] for r in res])
+    assert rel_err(d, d_ref) <= 1e-3 and rel_err(c, c_ref) <= 1e-3, (rel_err(d, d_ref), rel_err(c, c_ref))
