@@ -294,3 +294,22 @@ def test_large_backbone_state_dict_matches_reference_layout():
         assert tuple(sd[k].shape) == tuple(shape) and sd[k].dtype == dtype, k
     assert create_model(dict(cfg, backbone_size="huge", backbone_config={"image_size": 56, "num_hidden_layers": 1})
                         ).feature_dim == 768          # unknown sizes fall back to base (:811-812)
+
+
+def test_decoded_pixel_view_outlives_the_image_object(tmp_path):
+    """The batch loop's decode hands out a view of Pillow's own pixel memory where it can; the view must keep that
+    memory alive after every reference to the image is gone and other images have been decoded since."""
+    import gc
+    from PIL import Image
+    from cognitive_aim_depth_estimation_amd.inference import CognitiveAimInference
+    rng = np.random.default_rng(4)
+    ref = rng.integers(0, 256, size=(300, 400, 3), dtype=np.uint8)
+    p = str(tmp_path / "a.png")
+    Image.fromarray(ref, "RGB").save(p)
+    views = [CognitiveAimInference._decode(None, p)[0] for _ in range(8)]
+    gc.collect()
+    junk = [np.asarray(Image.fromarray(rng.integers(0, 256, size=(300, 400, 3), dtype=np.uint8), "RGB").copy()) for _ in range(32)]
+    gc.collect()
+    for v in views:
+        assert v.shape[:2] == (300, 400) and np.array_equal(v[:, :, :3], ref)
+    del junk
