@@ -164,6 +164,8 @@ def main():
                     help="headline operand type (the headline configuration is bf16); the other one is timed beside it")
     ap.add_argument("--streams", type=int, default=0,
                     help="sub-batches the model runs on streams of its own (0 = the model's default, 2)")
+    ap.add_argument("--scores-in-memory", type=int, default=0,
+                    help="largest patch grid whose fp32 focal scores are kept in memory (0 = the model's default, 1536)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--no-second-dtype", action="store_true")
@@ -207,6 +209,8 @@ def main():
                "focal_config": {"num_iterations": args.iters, "focus_strength": 1.5}, "init_seed": 0}
         if args.streams > 0:
             cfg["streams"] = args.streams
+        if args.scores_in_memory > 0:
+            cfg["focal_scores_in_memory_max_patches"] = args.scores_in_memory
         cfg.update(extra)
         return cfg
 
