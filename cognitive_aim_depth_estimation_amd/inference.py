@@ -546,6 +546,11 @@ class CognitiveAimInference:
 
             def finish(item):
                 ins, good, dc_host, ev, heat, K, imgs = item
+                if hasattr(ev, "result"):            # a forward_async handle: collect, then bring the rows over
+                    depth, conf = ev.result()
+                    dc_host.copy_(torch.cat([depth, conf], dim=1)[None].float(), non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(self.device))
                 ev.synchronize()
                 for j, (path, reqs, exif_raw, size) in enumerate(good):
                     for k, name in enumerate(ins):
@@ -582,6 +587,22 @@ class CognitiveAimInference:
                     x = slot["x"][:b]
                     if hasattr(self.model, "_last_attention_weights"):
                         delattr(self.model, "_last_attention_weights")          # reference demo.py:334-335
+                    if ins == (None,) and not self.render and not getattr(self.model, "faithful_curiosity", False):
+                        # plain predictions, nothing to draw: two chunks in flight (the focal / tail part of one
+                        # under the backbone of the next); the rows are collected when the next chunk is queued
+                        handle = self.model.forward_async(x, exif)
+                        done = handle.done_event
+                        if done is None:
+                            done = torch.cuda.Event()
+                            done.record(cur)
+                        slot["free"] = done
+                        timing["consumer_forward_issue_s"] += clock() - t0
+                        t0 = clock()
+                        if pending is not None:
+                            finish(pending)
+                        timing["consumer_results_s"] += clock() - t0
+                        pending = (ins, good, slot["dc"][: b * 2].view(1, b, 2), handle, None, 1, None)
+                        continue
                     if ins == (None,):
                         depth, conf = self.model(x, exif)
                         attn = self.model.get_attention_weights()

@@ -196,6 +196,38 @@ def _init_tensor(key: str, shape, dtype, gen: torch.Generator) -> torch.Tensor:
     return torch.randn(shape, generator=gen) * 0.02
 
 
+class _Pending:
+    """Handle of CognitiveAimModel.forward_async."""
+
+    def __init__(self, model, outs, done, stream, return_attention, ready=None):
+        self._model, self._outs, self._done, self._stream = model, outs, done, stream
+        self._return_attention, self._ready = return_attention, ready
+
+    @property
+    def done_event(self):
+        """Event after the batch's last kernel (None when the call ran synchronously)."""
+        return self._done
+
+    def result(self):
+        """(depth, conf[, attention]) as forward returns them, valid on the caller's current stream."""
+        if self._ready is not None:
+            return self._ready
+        depth, conf, attn, fused = self._outs
+        cur = torch.cuda.current_stream(depth.device)
+        cur.wait_event(self._done)
+        for t in (depth, conf, attn, fused):
+            if t is not None:
+                t.record_stream(cur)
+        m = self._model
+        m.fusion_features = fused
+        if m.use_focal and not hasattr(m, "_last_attention_weights"):
+            m._last_attention_weights = attn
+        elif not m.use_focal:
+            m._last_attention_weights = None
+        self._ready = (depth, conf, attn) if self._return_attention else (depth, conf)
+        return self._ready
+
+
 class _Node(nn.Module):
     """Bare container: exists only to give parameters the reference's dotted names."""
 
@@ -253,8 +285,10 @@ class CognitiveAimModel(nn.Module):
         # Batches of 2 x 8 images or more are run as `streams` sub-batches on streams of the model's own: the kernel
         # boundaries, partial last rounds and store-bound epilogues of one sub-batch's launches fill with the other's
         # work (same-box A/B at B = 32, 518 pixels: 2 streams +2 %: each half's GEMMs run 12 % slower than the whole
-        # batch's, the LayerNorm / focal / tail time hides).  Per-image
-        # results do not depend on batch mates, so the outputs are bit-identical to a single-stream run.
+        # batch's, the LayerNorm / focal / tail time hides).  Per-image results do not depend on batch mates; they
+        # are bit-identical to a single-stream run unless a GEMM K-splits its partial last round of tiles (K = 3072 at
+        # production sizes: which rows lie in that round depends on the row count, and a split tile sums its K in
+        # slices -- the same value to fp32 rounding).
         self.num_streams = max(1, int(config.get("streams", os.environ.get("COGAIM_STREAMS", "2"))))
         self._side_streams = None
         # Opt-in: evaluate the curiosity module wherever the reference does (src/model.py:995, :1104, :1139, :1185),
@@ -757,7 +791,9 @@ class CognitiveAimModel(nn.Module):
         elif entry == "seen":
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(g):
+            # thread_local: other host threads (the batch loop's uploader) keep issuing copies, allocations and event
+            # waits on their own streams while this thread records; only this thread's calls belong to the capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 body()
             graphs[key] = g
             g.replay()
@@ -866,6 +902,39 @@ class CognitiveAimModel(nn.Module):
         if return_attention:
             return depth, conf, attn
         return depth, conf
+
+    @torch.no_grad()
+    def forward_async(self, images, exif_data=None, return_attention=False):
+        """``forward`` for loops that can keep two batches in flight (no counterpart in the reference).
+
+        Returns at once with a handle; ``handle.result()`` gives what ``forward`` returns and makes the caller's
+        current stream wait for it.  Calls alternate between two streams of the model's own, each running the WHOLE
+        batch (its GEMMs at full height), so the focal / tail part of one batch lies under the backbone of the next:
+        ``forward`` cannot do that, because its outputs have to be valid on the caller's stream when it returns and
+        the next call's inputs are only known to be ready at that stream's tail.  The caller keeps ``images`` and
+        ``exif_data`` alive and unchanged until ``result()``; results are collected in call order."""
+        if self.faithful_curiosity:
+            raise RuntimeError("forward_async keeps batches in flight out of order with the host's random stream; "
+                               "faithful_curiosity needs forward()")
+        if not (images.dim() == 4 and images.is_cuda) or images.shape[0] == 0:
+            return _Pending(self, None, None, None, return_attention, ready=self.forward(images, exif_data, return_attention))
+        dev = images.device
+        slots = getattr(self, "_async_streams", None)
+        if slots is None or slots[0].device != dev:
+            slots = self._async_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            self._async_turn = 0
+        st = slots[self._async_turn]
+        self._async_turn ^= 1
+        cur = torch.cuda.current_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(cur)                      # the inputs as the caller's stream has them NOW
+        st.wait_event(ready)
+        images.record_stream(st)
+        with torch.cuda.stream(st):
+            outs = self._forward_core(images, exif_data)
+            done = torch.cuda.Event()
+            done.record(st)
+        return _Pending(self, outs, done, st, return_attention)
 
     @torch.no_grad()
     def forward_with_guidance(self, images, exif_data=None, attention_guidance=None, return_attention=False,

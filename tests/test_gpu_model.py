@@ -604,3 +604,28 @@ def test_degenerate_attention_without_scores_in_memory_is_reported():
     with _pt.raises(RuntimeError, match="degenerate"):
         model.synchronize()
     model.synchronize()
+
+
+def test_forward_async_two_batches_in_flight():
+    """forward_async: handles collected in call order give what forward gives (bit for bit at these sizes), with two
+    batches in flight on the model's two streams, different batch shapes interleaved, attention on request."""
+    model, sd = synth_model_and_sd(2, 4, seed=7, dtype="fp16")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    xs = [torch.randn(b, 3, s, s, device="cuda", generator=g) for b, s in ((5, 98), (3, 56), (5, 98), (17, 70), (5, 98))]
+    exifs = [default_exif(x.shape[0], "cuda") for x in xs]
+    want = [model(x, e, return_attention=True) for x, e in zip(xs, exifs)]
+    for rep in range(3):                                             # eager, capture, replay on each stream
+        handles = []
+        got = []
+        for x, e in zip(xs, exifs):
+            handles.append(model.forward_async(x, e, return_attention=True))
+            if len(handles) == 2:
+                got.append(handles.pop(0).result())
+        got += [h.result() for h in handles]
+        torch.cuda.synchronize()
+        for w, r in zip(want, got):
+            assert all(torch.equal(a, b) for a, b in zip(w, r)), rep
+    d_ref, c_ref = O.forward(sd, xs[0].cpu(), {k: v.cpu() for k, v in exifs[0].items()})
+    assert rel_err(got[0][0], d_ref) <= 1e-3 and rel_err(got[0][1], c_ref) <= 1e-3
+    assert model.forward_async(xs[1][:0], None).result()[0].shape == (0, 1)      # empty batch: nothing launched
+    model.synchronize()
