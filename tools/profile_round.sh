@@ -9,7 +9,7 @@ out=gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp 2>/dev/null && cd - >/dev/null
 export TMPDIR=/tmp
-B="--steps 3 --warmup 1 --no-cpu-baseline --no-second-dtype --no-kernel-profile $*"
+B="--steps 3 --warmup 1 --no-cpu-baseline --no-second-dtype --no-kernel-profile --no-pipelined $*"
 timeout -k 10 300 python3 bench.py $* > "$out/bench.json" 2> "$out/bench.err" || { echo "bench failed"; tail -5 "$out/bench.err"; exit 1; }
 timeout -k 10 240 rocprofv3 --kernel-trace --stats -d "$out/trace" -o t --output-format csv -- python3 bench.py $B > "$out/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$out/trace.log"; exit 1; }
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d "$out/fetch" -o t --output-format csv -- python3 bench.py $B > "$out/fetch.log" 2>&1 || { echo "fetch failed"; tail -5 "$out/fetch.log"; exit 1; }
