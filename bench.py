@@ -269,6 +269,20 @@ def main():
         "by_dtype": {args.dtype: {"value": round(value, 2), "ms_per_step": round(ms_per_step, 3),
                                   "mfma_frac_end_to_end": frac(value)}},
     }
+    props = torch.cuda.get_device_properties(dev)
+    khz = getattr(props, "clock_rate", 0)
+    if not khz:                    # torch does not carry it on this build: hipDeviceAttributeClockRate (enum value 5), kHz
+        try:
+            import ctypes
+            v = ctypes.c_int(0)
+            if ctypes.CDLL("libamdhip64.so").hipDeviceGetAttribute(ctypes.byref(v), 5, dev.index or 0) == 0:
+                khz = v.value
+        except OSError:
+            pass
+    out["device"] = {"name": props.name, "arch": getattr(props, "gcnArchName", ""), "compute_units": props.multi_processor_count,
+                     "max_clock_mhz": round(khz / 1000.0, 1),
+                     "peak_tflops_assumed": PEAK_TFLOPS,
+                     "peak_note": "256 CUs x 4096 FLOP per CU and clock x 2.4 GHz, dense 16-bit MFMA"}
     results = {args.dtype: (d, c)}
 
     if not args.no_second_dtype:
