@@ -357,6 +357,26 @@ def main():
                            "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src}
         out["mfma_frac_by_kernel"] = {f"{k[0]}{list(k[1])}": round(v[2] / (v[0] / v[1] * 1e-3) / 1e12 / PEAK_TFLOPS, 4)
                                       for k, v in top if v[2]}
+        if n_sub > 1:
+            # the same entry point with the WHOLE batch in one launch (what a single stream, or forward_async, runs):
+            # the figure comparable with a run that does not split the batch
+            _lib.PROFILE = []
+            for _ in range(3):
+                model(images, exif)
+            torch.cuda.synchronize()
+            prof, _lib.PROFILE = _lib.PROFILE, None
+            acc = [0.0, 0, 0.0, None]
+            for name, a, e0, e1 in prof:
+                fl, shape = gemm_flops(name, a)
+                if name == dname and fl and (acc[3] is None or shape == acc[3] or fl > acc[2]):
+                    if acc[3] is not None and shape != acc[3]:
+                        acc = [0.0, 0, fl, shape]
+                    acc[0] += e0.elapsed_time(e1); acc[1] += 1; acc[2] = fl; acc[3] = shape
+            if acc[1]:
+                ms = acc[0] / acc[1]
+                out["roofline"]["whole_batch_launch"] = {"kernel": f"{dname}{list(acc[3])}", "avg_launch_ms": round(ms, 4),
+                                                         "achieved": round(acc[2] / (ms * 1e-3) / 1e12, 1),
+                                                         "frac": round(acc[2] / (ms * 1e-3) / 1e12 / PEAK_TFLOPS, 4)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cogaim_oracle as O
