@@ -277,6 +277,27 @@ def exif_rows(exifs: Sequence[Optional[Dict]], camera_to_id: Dict[str, int]) -> 
             "iso": torch.tensor(iso, dtype=torch.float32), "camera_idx": torch.tensor(cam, dtype=torch.long)}
 
 
+def host_thread_budget() -> Tuple[int, int]:
+    """(decode threads, packer threads) of ONE rank's batch loop.  Every rank of a node runs its own loop, so the
+    host's cores are divided by the ranks the launcher started on this node (LOCAL_WORLD_SIZE): eight ranks that
+    each took 16 + 8 threads would put ~200 runnable threads on the cores of one host.  COGAIM_HOST_THREADS
+    overrides the per-rank core share (boxes whose os.cpu_count() shows more cores than the job may use)."""
+    try:
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    except ValueError:
+        local_world = 1
+    share = os.environ.get("COGAIM_HOST_THREADS")
+    if share is not None:
+        share = max(1, int(share))
+    else:
+        try:
+            cpus = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            cpus = os.cpu_count() or 4
+        share = max(1, cpus // local_world)
+    return max(1, min(16, share)), max(1, min(8, share // 2))
+
+
 def heatmap_postprocess(attn: torch.Tensor) -> torch.Tensor:
     """reference demo.py:533-552 for a whole batch on the device: cube, damp everything at or below the 70th
     percentile by 0.3, min-max normalise, lay out on the (zero padded) square grid.  attn [B,N] on the GPU ->
@@ -472,9 +493,40 @@ class CognitiveAimInference:
                       "exif_f": torch.empty(3, cap, dtype=torch.float32).pin_memory(),
                       "exif_i": torch.empty(cap, dtype=torch.int64).pin_memory(),
                       "exif_f_dev": torch.empty(3, cap, dtype=torch.float32, device=self.device),
-                      "exif_i_dev": torch.empty(cap, dtype=torch.int64, device=self.device)} for _ in range(3)]
+                      "exif_i_dev": torch.empty(cap, dtype=torch.int64, device=self.device)} for _ in range(4)]
+            # Slot ownership is explicit: the producer takes a slot only from `free_slots`, the consumer puts it
+            # back once the chunk's rows have been read (finish()), i.e. after the forward that read slot['x'] and
+            # the copy into slot['dc'] have completed; slot['free'] is that forward's last event and the producer's
+            # side stream waits on it before it overwrites the buffers.  Four slots: one finishing, one whose
+            # forward is queued, two for the producer (one being filled, one waiting in `ready`).
+            free_slots: "queue.Queue" = queue.Queue()
+            for sl in slots:
+                free_slots.put(sl)
             ready: "queue.Queue" = queue.Queue(maxsize=2)
+            stop = threading.Event()           # set by the consumer when it gives up: the producer then ends
             side = torch.cuda.Stream(device=self.device)
+
+            class _Stopped(Exception):
+                pass
+
+            def take_slot():
+                while True:
+                    if stop.is_set():
+                        raise _Stopped()
+                    try:
+                        return free_slots.get(timeout=0.1)
+                    except queue.Empty:
+                        continue
+
+            def hand_over(item):
+                while True:
+                    if stop.is_set():
+                        raise _Stopped()
+                    try:
+                        ready.put(item, timeout=0.1)
+                        return
+                    except queue.Full:
+                        continue
 
             timing = {"producer_wait_decode_s": 0.0, "producer_upload_preprocess_s": 0.0, "producer_wait_buffer_s": 0.0,
                       "consumer_wait_chunk_s": 0.0, "consumer_forward_issue_s": 0.0, "consumer_results_s": 0.0}
@@ -484,8 +536,9 @@ class CognitiveAimInference:
 
             def produce():
                 try:
-                    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool, \
-                            ThreadPoolExecutor(max_workers=8) as packers:
+                    n_decode, n_pack = host_thread_budget()
+                    with ThreadPoolExecutor(max_workers=n_decode) as pool, \
+                            ThreadPoolExecutor(max_workers=n_pack) as packers:
                         futs: Dict[int, list] = {}
                         for ci, (ins, files) in enumerate(chunks):
                             # decode at most three chunks ahead of the upload: decoded arrays (36 MB each for 12-MP
@@ -493,10 +546,12 @@ class CognitiveAimInference:
                             for cj in range(ci, min(ci + 4, len(chunks))):
                                 if cj not in futs:
                                     futs[cj] = [pool.submit(self._decode, f[0]) for f in chunks[cj][1]]
-                            slot = slots[ci % 3]
                             t0 = clock()
+                            slot = take_slot()
                             if slot["free"] is not None:
-                                slot["free"].synchronize()          # the forward that read this buffer has finished
+                                side.wait_event(slot["free"])       # orders the overwrite behind the last reader
+                                slot["free"].synchronize()          # the pinned rows are rewritten by the host
+                                slot["free"] = None
                             timing["producer_wait_buffer_s"] += clock() - t0
                             good, arrays = [], []
                             t0 = clock()
@@ -533,19 +588,30 @@ class CognitiveAimInference:
                                 ev.record(side)
                             timing["producer_wait_decode_s"] += t1 - t0
                             timing["producer_upload_preprocess_s"] += clock() - t1
-                            ready.put((ins, slot, good, ev, exif))
+                            hand_over((ins, slot, good, ev, exif))
+                except _Stopped:
+                    pass
                 except BaseException as e:            # surfaces in the consumer
                     failure.append(e)
                 finally:
-                    ready.put(None)
+                    try:
+                        hand_over(None)
+                    except _Stopped:
+                        pass
 
             torch.cuda.set_device(self.device)
-            worker = threading.Thread(target=produce, daemon=True)
+            worker = threading.Thread(target=produce, daemon=True, name="cogaim-producer")
             worker.start()
             pending = None                     # previous chunk: its rows are read once the next one is queued
 
             def finish(item):
-                ins, good, dc_host, ev, heat, K, imgs = item
+                ins, good, dc_host, ev, heat, K, imgs, slot = item
+                try:
+                    read_rows(ins, good, dc_host, ev, heat, K, imgs)
+                finally:
+                    free_slots.put(slot)       # its forward has completed and its rows have been read
+
+            def read_rows(ins, good, dc_host, ev, heat, K, imgs):
                 if hasattr(ev, "result"):            # a forward_async handle: collect, then bring the rows over
                     depth, conf = ev.result()
                     dc_host.copy_(torch.cat([depth, conf], dim=1)[None].float(), non_blocking=True)
@@ -601,7 +667,7 @@ class CognitiveAimInference:
                         if pending is not None:
                             finish(pending)
                         timing["consumer_results_s"] += clock() - t0
-                        pending = (ins, good, slot["dc"][: b * 2].view(1, b, 2), handle, None, 1, None)
+                        pending = (ins, good, slot["dc"][: b * 2].view(1, b, 2), handle, None, 1, None, slot)
                         continue
                     if ins == (None,):
                         depth, conf = self.model(x, exif)
@@ -635,7 +701,9 @@ class CognitiveAimInference:
                     if pending is not None:
                         finish(pending)
                     timing["consumer_results_s"] += clock() - t0
-                    pending = (ins, good, dc_host, done, heat, K, imgs)
+                    pending = (ins, good, dc_host, done, heat, K, imgs, slot)
+                else:
+                    free_slots.put(slot)       # every file of the chunk failed to load: nothing was queued on it
             if pending is not None:
                 finish(pending)
             worker.join()
@@ -646,6 +714,17 @@ class CognitiveAimInference:
             # under torch.distributed every rank must still reach the collective below; this rank's
             # unfinished rows stay NaN there and the error is raised afterwards
             failure.append(e)
+            # end the producer: it polls `stop` wherever it could block, so it neither stays parked on a full
+            # queue nor keeps the device buffers and thread pools of this call alive
+            if "stop" in locals():
+                stop.set()
+                try:
+                    while True:
+                        ready.get_nowait()
+                except queue.Empty:
+                    pass
+                if "worker" in locals() and worker.is_alive():
+                    worker.join(timeout=30)
         if world > 1:
             everyone = gather_shards(local.to(self.device), n).cpu()
             for i in range(n):

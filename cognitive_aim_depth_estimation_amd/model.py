@@ -301,6 +301,16 @@ class CognitiveAimModel(nn.Module):
         self.faithful_curiosity = bool(config.get("faithful_curiosity", False)) and not large
         # largest patch grid whose fp32 focal scores are kept in memory (see _workspace); tests lower it
         self.scores_in_memory_max_patches = int(config.get("focal_scores_in_memory_max_patches", 1536))
+        # Outward error behaviour.  The reference swallows every exception of its feature extraction and carries on
+        # with all-zero fused features (src/model.py:1050-1056), and answers any exception of the guided forward with
+        # the standard forward (:1237-1240).  Errors found on the HOST before anything is launched -- an EXIF dict
+        # without one of its four keys or with the wrong number of entries, a guidance tensor that cannot be laid out
+        # on the patch grid -- are treated the same way unless ``strict_errors`` is set; then they raise.  Kernel
+        # launch errors and device-side conditions always raise.
+        self.strict_errors = bool(config.get("strict_errors", False))
+        # workspaces (one per batch shape and stream, each with its captured graphs) kept before the least recently
+        # used one is dropped; ~1 GB each at 32 images of 518 x 518
+        self.workspace_cache = max(1, int(config.get("workspace_cache", 12)))
         # replay the per-shape launch sequence as one HIP graph after its first (eager) run
         self.use_graph = bool(config.get("use_hip_graph", os.environ.get("COGAIM_GRAPH", "1") != "0"))
 
@@ -330,7 +340,11 @@ class CognitiveAimModel(nn.Module):
     # ------------------------------------------------------------------ packing
     # The 16-bit GEMM copies of the weights are rebuilt when the weights change.  Every nn.Module route that
     # replaces or rewrites parameters goes through _apply (.to / .cuda / .float ...) or load_state_dict, which
-    # bump an epoch; code that edits a parameter tensor in place calls refresh_weights() itself.
+    # bump an epoch; in-place edits of a parameter (p.mul_(..) under no_grad, nn.init.*_(p), a write through a
+    # state_dict() alias) and re-pointed storage (p.data = t) are caught by the per-parameter (version counter,
+    # address) pairs that _signature() compares on every call (~0.06 ms of host time for the ~270 tensors of the
+    # base model).  The one route torch itself cannot see is an in-place write through ``p.data`` (that view has a
+    # version counter of its own): such code calls refresh_weights().
     def _apply(self, fn, *a, **k):
         self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
         return super()._apply(fn, *a, **k)
@@ -340,16 +354,24 @@ class CognitiveAimModel(nn.Module):
         return super().load_state_dict(*a, **k)
 
     def refresh_weights(self):
-        """Call after modifying parameter tensors in place (``p.data.mul_(..)``): the packed 16-bit copies and
-        the captured launch graphs are rebuilt on the next forward."""
+        """Forces the packed 16-bit copies and the captured launch graphs to be rebuilt on the next forward.
+        In-place edits of parameters are noticed without it (see _signature); it remains for writes that bypass
+        torch's version counter: ``p.data.mul_(..)`` / ``p.data.copy_(..)`` (the ``.data`` view counts versions of
+        its own) or a kernel of the caller's writing through ``data_ptr()``."""
         self._weights_epoch += 1
 
     def _signature(self):
-        return (self.compute_dtype, self._weights_epoch)
+        params = self.__dict__.get("_param_list")
+        if params is None or self.__dict__.get("_param_list_epoch") != self._weights_epoch:
+            params = [p for p in self.parameters()]
+            self.__dict__["_param_list"], self.__dict__["_param_list_epoch"] = params, self._weights_epoch
+        return (self.compute_dtype, self._weights_epoch, tuple((p._version, p.data_ptr()) for p in params))
 
     def _pack(self):
         """16-bit copies of the GEMM weights, fused QK matrices; refreshed whenever a
         parameter was replaced or modified in place (load_state_dict, .to())."""
+        if self._packed is not None and self.__dict__.get("_sig_fresh"):
+            return self._packed                # checked by the public call that is running (see _forward_split)
         sig = self._signature()
         if self._packed is not None and sig == self._packed_sig:
             return self._packed
@@ -411,6 +433,9 @@ class CognitiveAimModel(nn.Module):
         for ws in self._ws.values():          # captured graphs hold the old weight pointers
             ws.pop("graphs", None)
         self._tab.clear()
+        # The conversions above were queued on the caller's current stream; forwards run on other streams too
+        # (sub-batch streams, forward_async).  Packing is rare, so it simply completes before anything reads it.
+        torch.cuda.current_stream(dev).synchronize()
         return pk
 
     def _focal_prefixes(self):
@@ -444,10 +469,14 @@ class CognitiveAimModel(nn.Module):
         key = (B, gh, gw, self.compute_dtype, stream_ptr())
         ws = self._ws.get(key)
         if ws is not None:
+            self._ws[key] = self._ws.pop(key)          # most recently used last
             return ws
-        if len(self._ws) > 8:
-            self.synchronize()
-            self._ws.clear()
+        while len(self._ws) >= self.workspace_cache:
+            # evict the least recently used workspace only (with it its captured graphs); the others keep theirs, so
+            # a directory of mixed resolutions re-captures the shape that fell out, not every shape
+            old = self._ws.pop(next(iter(self._ws)))
+            old["stream"].synchronize()
+            self._examine_flags(old)
         dev = self._packed["device"]
         _, tdt = _DTYPES[self.compute_dtype]
         D, H = self.feature_dim, self.num_heads
@@ -468,6 +497,7 @@ class CognitiveAimModel(nn.Module):
         big_bytes = max(M * 4 * D * 2, B * N * self._packed["pe_kp"] * 2,
                         B * N * ldS * 4 if (self.use_focal and not tiled) else 0)
         ws = {
+            "stream": torch.cuda.current_stream(dev),
             "N": N, "T": T, "M": M, "Tp": Tp, "ldS": ldS, "nblk": nblk, "tiled": tiled, "parts": parts,
             "pstat": torch.empty(2, B * N * parts, **f32) if (tiled and self.use_focal) else None,
             "x": torch.empty(M, D, **f32), "tokens": torch.empty(M, D, **f32),
@@ -662,6 +692,19 @@ class CognitiveAimModel(nn.Module):
         self._linear(ptr(ws["t256"]), 256, "ambient_stream.mlp.3", ptr(ws["t128"]), 128, B, act=1)
         self._linear(ptr(ws["t128"]), 128, "ambient_stream.mlp.5", ws["cat"].data_ptr() + col * 4, 192, B)
 
+    @staticmethod
+    def _exif_check(exif_data, B: int):
+        """Host-only validation of an EXIF dict (nothing is launched, nothing copied): the four vectors of
+        src/model.py:491-508 are present, are tensors and hold one entry per image."""
+        if not isinstance(exif_data, dict):
+            raise TypeError(f"exif_data must be a dict of tensors, got {type(exif_data).__name__}")
+        for k in ("camera_idx", "focal_length", "aperture", "iso"):
+            t = exif_data[k]                                  # KeyError, as in the reference
+            if not torch.is_tensor(t):
+                raise TypeError(f"exif_data['{k}'] must be a tensor")
+            if t.numel() != B:
+                raise ValueError(f"exif_data['{k}'] has {t.numel()} entries for a batch of {B}")
+
     def _exif_inputs(self, exif_data: dict, B: int):
         """Validated device copies of the four EXIF vectors ([B] or [B,1], src/model.py:491-508)."""
         dev = self._packed["device"]
@@ -692,9 +735,10 @@ class CognitiveAimModel(nn.Module):
         self._linear(ptr(ws["exf"]), 128, "exif_prior.fusion.0", ptr(ws["t256"]), 256, B, act=1)
         self._linear(ptr(ws["t256"]), 256, "exif_prior.fusion.3", ws["cat"].data_ptr() + col * 4, 192, B)
 
-    def _heads(self, ws, B):
+    def _heads(self, ws, B, fuse=True):
         f = self._packed["f32"]
-        self._linear(ptr(ws["cat"]), 192, "fusion.0", ptr(ws["fused"]), 192, B, act=1)
+        if fuse:
+            self._linear(ptr(ws["cat"]), 192, "fusion.0", ptr(ws["fused"]), 192, B, act=1)
         out = ws["out"]
         call("cogaim_heads", ptr(ws["fused"]), 192, ptr(f["decision_head.0.weight"]), ptr(f["decision_head.0.bias"]),
              ptr(f["confidence_head.0.weight"]), ptr(f["confidence_head.0.bias"]),
@@ -730,6 +774,14 @@ class CognitiveAimModel(nn.Module):
     @torch.no_grad()
     def get_features_aligned(self, images, exif_data=None):
         """Fused 192-d features (reference src/model.py:960-1056), one pass."""
+        if exif_data is not None and self.use_exif and images.dim() == 4:
+            try:
+                self._exif_check(exif_data, images.shape[0])
+            except Exception as e:
+                if self.strict_errors:
+                    raise
+                print(f"get_features_aligned exception: {e!r}")
+                return torch.zeros(images.shape[0], self.fusion_dim, device=images.device)     # :1054
         images, ws, B = self._prepare(images)
         self._features(images, exif_data, ws, B, graph_key="features")
         self._check_fallback_flags(ws)
@@ -851,17 +903,25 @@ class CognitiveAimModel(nn.Module):
              hist.numel(), st)
         return cw["reward"]
 
-    def _forward_core(self, images, exif_data, curiosity_calls=0):
+    def _forward_core(self, images, exif_data, curiosity_calls=0, zero_features=False):
         images, ws, B = self._prepare(images)
         draws = [self._curiosity_draw(B) for _ in range(curiosity_calls)]
-        self._features(images, exif_data, ws, B, graph_key="forward")
+        if zero_features:
+            # the reference's backup features (src/model.py:1050-1056): depth and confidence come from all-zero
+            # fused features, the attention map (:1093-1113) still from the images
+            if self.use_ambient or self.use_focal:
+                self._features(images, None, ws, B, graph_key="forward")
+            ws["fused"].zero_()
+            self._heads(ws, B, fuse=False)
+        else:
+            self._features(images, exif_data, ws, B, graph_key="forward")
         for dr in draws:
             self._curiosity_run(ws, B, dr)
         depth, conf = self._outputs(ws)
         self._check_fallback_flags(ws)
         return depth, conf, (ws["attn"].clone() if self.use_focal else None), ws["fused"].clone()
 
-    def _forward_split(self, images, exif_data, n):
+    def _forward_split(self, images, exif_data, n, zero_features=False):
         """The batch as n contiguous sub-batches, each on a stream of the model's own (its own workspace and
         captured graph); the caller's stream waits for all of them."""
         B = images.shape[0]
@@ -871,11 +931,16 @@ class CognitiveAimModel(nn.Module):
         cur = torch.cuda.current_stream(dev)
         bounds = [(B * i // n, B * (i + 1) // n) for i in range(n)]
         outs = []
-        for st, (lo, hi) in zip(self._side_streams, bounds):
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                ex = None if exif_data is None else {k: v[lo:hi] for k, v in exif_data.items()}
-                outs.append(self._forward_core(images[lo:hi], ex))
+        self._pack()                           # on the caller's stream, once for all sub-batches
+        self.__dict__["_sig_fresh"] = True
+        try:
+            for st, (lo, hi) in zip(self._side_streams, bounds):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    ex = None if exif_data is None else {k: v[lo:hi] for k, v in exif_data.items()}
+                    outs.append(self._forward_core(images[lo:hi], ex, zero_features=zero_features))
+        finally:
+            self.__dict__["_sig_fresh"] = False
         for st in self._side_streams[:n]:
             cur.wait_stream(st)
         return tuple(None if outs[0][i] is None else torch.cat([o[i] for o in outs]) for i in range(4))
@@ -890,10 +955,19 @@ class CognitiveAimModel(nn.Module):
         if self.faithful_curiosity and self.use_focal:        # :995, :1104 (first call only), :1139
             calls = 1 + int(not hasattr(self, "_last_attention_weights")) + int(bool(return_attention))
             n = 1                                             # whole-batch draws, in the reference's order
+        zero = False
+        if exif_data is not None and self.use_exif and images.dim() == 4:
+            try:
+                self._exif_check(exif_data, images.shape[0])
+            except Exception as e:
+                if self.strict_errors:
+                    raise
+                print(f"get_features_aligned exception: {e!r}")      # the reference's message (:1051)
+                zero, exif_data = True, None
         if n > 1:
-            depth, conf, attn, fused = self._forward_split(images, exif_data, n)
+            depth, conf, attn, fused = self._forward_split(images, exif_data, n, zero)
         else:
-            depth, conf, attn, fused = self._forward_core(images, exif_data, calls)
+            depth, conf, attn, fused = self._forward_core(images, exif_data, calls, zero)
         self.fusion_features = fused
         if self.use_focal and not hasattr(self, "_last_attention_weights"):
             self._last_attention_weights = attn          # :1093-1113
@@ -925,6 +999,7 @@ class CognitiveAimModel(nn.Module):
             self._async_turn = 0
         st = slots[self._async_turn]
         self._async_turn ^= 1
+        self._pack()                           # on the caller's stream: the model's own streams only read the copies
         cur = torch.cuda.current_stream(dev)
         ready = torch.cuda.Event()
         ready.record(cur)                      # the inputs as the caller's stream has them NOW
@@ -963,11 +1038,29 @@ class CognitiveAimModel(nn.Module):
                     self._last_attention_weights = out[2]
                 return out if return_attention else out[:2]
             return self.forward(images, exif_data, return_attention)
+        exif_bad = None
+        try:            # everything in here is host work: nothing has been launched when it raises
+            p = self.patch_size
+            if images.dim() == 4:
+                g = tables.guidance_vector(attention_guidance, (images.shape[2] // p) * (images.shape[3] // p))
+                if g.numel() != (images.shape[2] // p) * (images.shape[3] // p):
+                    raise ValueError("attention_guidance cannot be resized to the patch grid")
+            if exif_data is not None and self.use_exif and images.dim() == 4:
+                try:
+                    self._exif_check(exif_data, images.shape[0])
+                except Exception as e:
+                    if self.strict_errors:
+                        raise
+                    # the reference fails on the EXIF dict only after the guided attention has been formed and
+                    # cached (:1212, then :1216): keep that order
+                    exif_bad, exif_data = (exif_data, e), None
+        except Exception as e:
+            if self.strict_errors:
+                raise
+            print(f"Guided feature extraction failed: {e!r}")          # the reference's message (:1238)
+            return self.forward(images, exif_data, return_attention)
         images, ws, B = self._prepare(images)
         N, D, T = ws["N"], self.feature_dim, ws["T"]
-        g = tables.guidance_vector(attention_guidance, N)
-        if g.numel() != N:
-            raise ValueError("attention_guidance cannot be resized to the patch grid")
         gkey = ("mask", attention_guidance.lower(), math.isqrt(N)) if isinstance(attention_guidance, str) else None
         gdev = self._table(*gkey) if gkey else g.to(self._packed["device"]).contiguous()
         cdraw = self._curiosity_draw(B) if self.faithful_curiosity else None     # :1185, before the Linear of :1420
@@ -998,6 +1091,9 @@ class CognitiveAimModel(nn.Module):
         self._check_fallback_flags(ws)
         attn = ws["guided"].clone()
         self._last_attention_weights = attn                # :1212
+        if exif_bad is not None:
+            print(f"Guided feature extraction failed: {exif_bad[1]!r}")
+            return self.forward(images, exif_bad[0], return_attention)       # -> the all-zero backup features
         if ncols != 192:
             # the reference's fusion Linear(192,192) rejects the short concat and its except
             # branch re-runs the standard forward (:1226, :1237-1240); the guided attention stays cached

@@ -156,3 +156,115 @@ def test_mixed_image_modes_and_a_multi_block_image(workdir, tmp_path):
     d = torch.tensor([[r[0]] for r in res])
     c = torch.tensor([[r[1]] for r in res])
     assert rel_err(d, d_ref) <= 1e-3 and rel_err(c, c_ref) <= 1e-3, (rel_err(d, d_ref), rel_err(c, c_ref))
+
+
+@pytest.mark.parametrize("render", [False, True])
+def test_many_chunks_reuse_the_input_slots(workdir, tmp_path, monkeypatch, render):
+    """Eleven distinct files in chunks of two: six chunks over four input slots, so every slot is handed back and
+    refilled while later forwards are still queued.  Each file's result must be the one a single-image prediction
+    gives (a slot overwritten before its forward had read it would show up as another file's numbers), and with
+    rendering on, the pixels handed to the PNG writer must be that file's own preprocessed pixels."""
+    _, cfg, ckpt, sd = workdir
+    rng = np.random.default_rng(5)
+    files = []
+    for i in range(11):
+        p = str(tmp_path / f"many{i:02d}.png")
+        PIL.fromarray(rng.integers(0, 256, size=(60 + 7 * i, 90 - 3 * i, 3), dtype=np.uint8), "RGB").save(p)
+        files.append(p)
+    h = inf.CognitiveAimInference(cfg, ckpt, device="cuda", batch_size=2, render=render)
+    drawn = {}
+
+    def record(image_path, image_tensor, depth, conf, grid, instruction):
+        drawn[image_path] = image_tensor.clone()
+    monkeypatch.setattr(h, "_save_prediction_image", record)
+    res = h.predict_batch(files)
+    assert all(r[0] is not None for r in res)
+    d_ref, c_ref, _ = _oracle(sd, files)
+    d = torch.tensor([[r[0]] for r in res])
+    c = torch.tensor([[r[1]] for r in res])
+    assert rel_err(d, d_ref) <= 1e-3 and rel_err(c, c_ref) <= 1e-3, (rel_err(d, d_ref), rel_err(c, c_ref))
+    assert len(set(round(r[0], 6) for r in res)) == len(files)          # distinct inputs, distinct outputs
+    single = inf.CognitiveAimInference(cfg, ckpt, device="cuda", batch_size=1, render=False)
+    for p, r in zip(files, res):
+        d1, c1, _ = single.predict(p)
+        assert abs(d1 - r[0]) <= 2e-5 * abs(d1) and abs(c1 - r[1]) <= 2e-5, p
+    if render:
+        assert sorted(drawn) == sorted(files)
+        for p in files:
+            want = inf.preprocess_image(PIL.open(p).convert("RGB"), (SIZE, SIZE))
+            assert torch.equal(drawn[p].cpu(), want), p
+
+
+def test_consumer_failure_ends_the_producer_thread(workdir, monkeypatch):
+    """A forward that raises must not leave the upload thread parked on the hand-over queue (it would keep the
+    input slots, the pinned staging buffers and both thread pools alive)."""
+    import threading
+    paths, cfg, ckpt, sd = workdir
+    h = inf.CognitiveAimInference(cfg, ckpt, device="cuda", batch_size=1, render=False)
+
+    def boom(*a, **k):
+        raise RuntimeError("forward failed")
+    monkeypatch.setattr(h.model, "forward_async", boom)
+    with pytest.raises(RuntimeError, match="forward failed"):
+        h.predict_batch(paths * 3)
+    assert not [t for t in threading.enumerate() if t.name == "cogaim-producer" and t.is_alive()]
+
+
+def test_cli_end_to_end_with_a_nested_reference_style_config(tmp_path, monkeypatch, capsys):
+    """``demo.py --image F --instruction center`` and ``--image_dir D`` through inference.main (reference
+    demo.py:603-693) with a YAML laid out like the reference's own (everything under ``model:``, image_size 224):
+    the nested values are ignored exactly as the reference ignores them, so the model is dinov2-base with three
+    focal iterations; a checkpoint path that does not exist keeps the seeded initial weights (demo.py:148-150).
+    The printed depth must be what predict() returns for the same file under the same torch seed (the guided path
+    draws its Linear(768, 64) per call, src/model.py:1417-1422)."""
+    import re
+    monkeypatch.chdir(tmp_path)
+    cfg = {"experiment": {"name": "full_cognition_enhanced", "version": "v1.0"},
+           "model": {"backbone": "dinov2", "backbone_size": "base",
+                     "cognitive_modules": ["ambient_stream", "iterative_focal_stream", "exif_prior_database"],
+                     "curiosity_guided_attention": {"enable": True, "attention_heads": 8},
+                     "enable_focal_stream": False,
+                     "exif_config": {"num_cameras": 71, "exif_embedding_dim": 64},
+                     "focal_config": {"num_iterations": 2, "focus_strength": 0.1}},
+           "dataset": {"path": "dataset", "image_size": 224, "augmentation": True},
+           "training": {"batch_size": 8, "epochs": 20}}
+    cfg_path = tmp_path / "nested.yaml"
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    rng = np.random.default_rng(9)
+    img_dir = tmp_path / "imgs"
+    img_dir.mkdir()
+    files = []
+    for i in range(3):
+        p = img_dir / f"photo{i}.jpg"
+        PIL.fromarray(rng.integers(0, 256, size=(300 + 20 * i, 400, 3), dtype=np.uint8), "RGB").save(p, quality=92)
+        files.append(str(p))
+    argv = ["--config", str(cfg_path), "--checkpoint", str(tmp_path / "absent.pth")]
+    torch.manual_seed(123)
+    inf.main(argv + ["--image", files[0], "--instruction", "center"])
+    out = capsys.readouterr().out
+    assert "Continuing with randomly initialized weights" in out and "Inference completed!" in out
+    depth_cli = float(re.search(r"Depth value: ([0-9.eE+-]+)", out).group(1))
+    conf_cli = float(re.search(r"Confidence: ([0-9.eE+-]+)", out).group(1))
+    assert "Guidance instruction: center" in out
+    assert os.path.exists(os.path.join("demo_results", "photo0_center_prediction.png")) or "skipped" in out
+    engine = inf.CognitiveAimInference(str(cfg_path), str(tmp_path / "absent.pth"), "cuda", 32, render=False)
+    m = engine.model
+    assert (m.num_layers, m.feature_dim, m.num_iterations, m.focus_strength) == (12, 768, 3, 1.5)   # nested values unread
+    assert engine.image_size == (224, 224)
+    torch.manual_seed(123)
+    d, c, meta = engine.predict(files[0], "center")
+    assert abs(d - depth_cli) <= 5e-5 * max(1.0, abs(d)) + 5e-5 and abs(c - conf_cli) <= 1e-4
+    assert meta["processed_size"] == (224, 224) and meta["instruction"] == "center"
+    # directory mode: every file through one batched forward
+    capsys.readouterr()
+    inf.main(argv + ["--image_dir", str(img_dir), "--no_render"])
+    out = capsys.readouterr().out
+    assert "Found 3 images" in out and "Successfully processed: 3" in out and "Failed: 0" in out
+    rows = engine.predict_batch(files)
+    avg = float(np.mean([r[0] for r in rows]))
+    assert abs(float(re.search(r"Average depth: ([0-9.]+)", out).group(1)) - avg) <= 1e-3 * avg + 1e-4
+    # the reference's argument checks
+    with pytest.raises(ValueError):
+        inf.main(argv)
+    with pytest.raises(ValueError):
+        inf.main(argv + ["--image", files[0], "--image_dir", str(img_dir)])

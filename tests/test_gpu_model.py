@@ -14,13 +14,14 @@ from tests.util import default_exif, load_golden, rel_err, synth_model_and_sd  #
 torch.set_grad_enabled(False)
 
 # north-star bar: <= 1e-3 relative on fp32 depth / confidence, for both 16-bit operand types.
-# fp16 (11 significand bits) sits at 1-2e-4.  bf16 (8 bits) sits at 4-6e-4 on the 12-layer 518-pixel geometry
-# the bar is quoted on, where the outputs average over 1369 tokens; on the 2-layer, 16..256-token golden
-# configurations the same rounding noise averages over far fewer terms (0.7-1.0e-3 measured; the reference's own
-# bf16 autocast is 1.8e-3 off its fp32 result), so those hold bf16 to 1.5e-3 and say so here.
-# Attention maps: measured max element-wise relative error x 2 (fp16 4e-3 .. 1.3e-2, bf16 3.5e-2 .. 6.3e-2).
+# fp16 (11 significand bits) sits at 1-3e-4.  bf16 (8 bits) sits at 2-7e-4 on the 518-pixel geometry the bar is
+# quoted on, where the outputs average over 1369 tokens.  Toy-geometry exception, bf16 only: on the 2-layer,
+# 16..256-token golden configurations the same rounding noise averages over far fewer terms (4.7e-4 .. 9.8e-4
+# measured; the reference's own bf16 autocast is 1.8e-3 off its fp32 result), so those hold bf16 to 1.2e-3
+# (measured x 1.2) and say so here.
+# Attention maps: measured max element-wise relative error x 1.5 (fp16 3e-3 .. 9e-3, bf16 2.3e-2 .. 4.3e-2).
 DEPTH_TOL = 1e-3
-TOL = {"fp16": dict(depth=1e-3, depth_small=1e-3, attn=1.5e-2), "bf16": dict(depth=1e-3, depth_small=1.5e-3, attn=0.13)}
+TOL = {"fp16": dict(depth=1e-3, depth_small=1e-3, attn=1.5e-2), "bf16": dict(depth=1e-3, depth_small=1.2e-3, attn=0.065)}
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.jsonl")
 
 
@@ -119,13 +120,85 @@ def test_full_size_vs_oracle(dtype):
     e = dict(depth=rel_err(d, d_ref), conf=rel_err(c, c_ref), attn=rel_err(a, a_ref))
     report(test="full_size", dtype=dtype, depth_ref=d_ref.flatten().tolist(), depth_gpu=d.flatten().tolist(), **e)
     assert e["depth"] <= TOL[dtype]["depth"] and e["conf"] <= TOL[dtype]["depth"], e     # the 1e-3 bar, both types
-    assert e["attn"] <= {"fp16": 1e-2, "bf16": 8e-2}[dtype], e
+    assert e["attn"] <= {"fp16": 1e-2, "bf16": 5e-2}[dtype], e          # measured 5.4e-3 / 3.3e-2
     _, _, g_ref = O.forward_with_guidance(sd, x, exif, "bottom-right")
     _, _, g = model.forward_with_guidance(x.cuda(), {k: v.cuda() for k, v in exif.items()}, "bottom-right",
                                           return_attention=True)
     gerr = float((g.cpu() - g_ref).abs().max() / g_ref.max())
     report(test="full_size_guided", dtype=dtype, attn_max_err_rel_peak=gerr)
     assert gerr <= 1e-2
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_production_batch_both_sub_batches_vs_oracle(dtype):
+    """BASELINE config 2 as it is benchmarked: B = 32 at 518 x 518, 12 layers, run as two sub-batches of 16 on the
+    model's two streams, graph-replayed (third call).  Four images of EACH half against the CPU oracle: the halves
+    have their own launches (row counts, partial last rounds of tiles, K-split tails), so one half passing says
+    nothing about the other."""
+    model, sd = synth_model_and_sd(12, 37, seed=11, dtype=dtype)
+    assert model.num_streams == 2
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(32, 3, 518, 518, generator=g)
+    exif = default_exif(32)
+    pick = torch.tensor([0, 5, 10, 15, 16, 21, 26, 31])
+    d_ref, c_ref, a_ref = O.forward(sd, x[pick], {k: v[pick] for k, v in exif.items()}, return_attention=True)
+    xg, eg = x.cuda(), {k: v.cuda() for k, v in exif.items()}
+    outs = [model(xg, eg, return_attention=True) for _ in range(3)]          # eager, capture, replay
+    d, c, a = outs[-1]
+    assert all(isinstance(v.get("graphs", {}).get(("forward", True, True)), torch.cuda.CUDAGraph) for v in model._ws.values())
+    assert len(model._ws) == 2
+    assert all(torch.equal(outs[0][i], outs[2][i]) for i in range(3))         # replay == eager launches
+    for name, sel in (("first", slice(0, 4)), ("second", slice(4, 8))):
+        e = dict(depth=rel_err(d[pick[sel]], d_ref[sel]), conf=rel_err(c[pick[sel]], c_ref[sel]),
+                 attn=rel_err(a[pick[sel]], a_ref[sel]))
+        report(test="production_batch", dtype=dtype, half=name, **e)
+        assert e["depth"] <= 1e-3 and e["conf"] <= 1e-3, (name, e)
+        assert e["attn"] <= {"fp16": 1e-2, "bf16": 5e-2}[dtype], (name, e)
+    assert float(c_ref.std()) > 1e-4                                          # a live confidence head (synthetic weights)
+    model.synchronize()
+
+
+def test_host_side_errors_follow_the_reference_unless_strict():
+    """EXIF dicts the reference would choke on (a missing key, a wrong entry count) and a guidance tensor that cannot
+    be laid out on the grid: the reference's blanket handlers turn these into all-zero fused features
+    (src/model.py:1050-1056: depth = softplus(decision bias), confidence from the head's biases alone) or into the
+    standard forward (:1237-1240); ``strict_errors`` raises instead.  Kernel errors are not part of this."""
+    from cognitive_aim_depth_estimation_amd import create_model
+    model, sd = synth_model_and_sd(2, 4, seed=7, dtype="fp16")
+    x = torch.randn(3, 3, 56, 56, device="cuda")
+    exif = default_exif(3, "cuda")
+    d_ok, c_ok, a_ok = model(x, exif, return_attention=True)
+    bad = {k: v for k, v in exif.items() if k != "iso"}
+    d, c, a = model(x, bad, return_attention=True)
+    zeros = torch.zeros(3, 192)
+    want_d = torch.nn.functional.softplus(zeros @ sd["decision_head.0.weight"].t() + sd["decision_head.0.bias"])
+    want_c = torch.sigmoid(torch.relu(zeros @ sd["confidence_head.0.weight"].t() + sd["confidence_head.0.bias"])
+                           @ sd["confidence_head.2.weight"].t() + sd["confidence_head.2.bias"])
+    assert rel_err(d, want_d) <= 1e-6 and rel_err(c, want_c) <= 1e-6
+    assert torch.equal(a, a_ok) and float(model.fusion_features.abs().max()) == 0.0
+    assert float(model.get_features(x, bad).abs().max()) == 0.0
+    short = dict(exif, aperture=exif["aperture"][:2])
+    d2, _ = model(x, short)
+    assert torch.equal(d2, d)
+    # guided: unusable guidance -> the standard forward; bad EXIF -> guided map cached, backup features
+    g_bad = torch.rand(200)                                   # 200 is no square: cannot be resized to 4 x 4
+    dg, cg = model.forward_with_guidance(x, exif, g_bad)
+    assert torch.equal(dg, d_ok) and torch.equal(cg, c_ok)
+    if hasattr(model, "_last_attention_weights"):
+        delattr(model, "_last_attention_weights")
+    dg2, _, ag2 = model.forward_with_guidance(x, bad, "left", return_attention=True)
+    cached = model.get_attention_weights()
+    _, _, a_left = model.forward_with_guidance(x, exif, "left", return_attention=True,
+                                               temp_projection=(torch.zeros(64, 768), torch.zeros(64)))
+    assert torch.equal(dg2, d) and torch.equal(cached, a_left) and torch.equal(ag2, a_ok)
+    model.synchronize()
+    strict = create_model(dict(model.config, strict_errors=True), {"num_cameras": 71}, device="cuda")
+    with pytest.raises(KeyError):
+        strict(x, bad)
+    with pytest.raises(ValueError):
+        strict(x, short)
+    with pytest.raises(Exception):
+        strict.forward_with_guidance(x, exif, g_bad)
 
 
 @pytest.mark.parametrize("tiled", [False, True])
@@ -328,7 +401,7 @@ def test_fp16_range_guard_and_outlier_tokens():
             e = dict(depth=rel_err(d, d_ref), conf=rel_err(c, c_ref))
             report(test="range_stress", dtype=dtype, scale=scale, **e)
             assert torch.isfinite(d).all() and torch.isfinite(c).all()
-            tol = 1e-3 if dtype == "fp16" else 4e-3        # bf16 on this 2-layer, 16-token model: see TOL above
+            tol = 1e-3 if dtype == "fp16" else 1.5e-3      # bf16 on this 2-layer, 16-token model (measured 7.2e-4): see TOL above
             assert e["depth"] <= tol and e["conf"] <= tol, (dtype, scale, e)
 
 
@@ -490,9 +563,12 @@ def test_large_backbone_vs_reference(dtype):
         e = dict(depth=rel_err(d, torch.from_numpy(z[f"depth{size}"])), conf=rel_err(c, torch.from_numpy(z[f"conf{size}"])),
                  attn=rel_err(a, torch.from_numpy(z[f"attn{size}"])))
         report(test="large_backbone", dtype=dtype, size=size, **e)
-        # bf16 on 16 and 49 tokens: rounding noise of 1024-term dot products averaged over few tokens (1.5e-3 measured);
-        # the 1370-token geometry below holds both operand types to the 1e-3 bar
-        small = 1e-3 if dtype == "fp16" else 2e-3
+        # Toy-geometry exception, bf16 only: 24 layers of 1024-term dot products with 8-bit significands, averaged
+        # over 16 or 49 tokens instead of 1369 (measured 5.8e-4 at 56 pixels, 1.13e-3 at 98 pixels -- the one case over
+        # the 1e-3 bar; tests/precision_model.py shows no dominant rounding site, the noise of ~11 sites adds in
+        # quadrature and shrinks with the token count).  The 1370-token geometry below, which is the one the bar is
+        # quoted on, holds both operand types to 1e-3 (bf16 measured 6.1e-4).
+        small = 1e-3 if dtype == "fp16" else 1.4e-3
         assert e["depth"] <= small and e["conf"] <= small, e
         assert e["attn"] <= TOL[dtype]["attn"], e
     proj = (torch.from_numpy(z["guided_proj_w"]), torch.from_numpy(z["guided_proj_b"]))

@@ -313,3 +313,250 @@ def test_decoded_pixel_view_outlives_the_image_object(tmp_path):
     for v in views:
         assert v.shape[:2] == (300, 400) and np.array_equal(v[:, :, :3], ref)
     del junk
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the batch loop itself on two ranks (gloo, CPU): sharding, a failing file on one rank, the gather
+# ---------------------------------------------------------------------------------------------------------------
+class _FakeEvent:
+    def record(self, *a, **k):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def query(self):
+        return True
+
+
+class _FakeStream:
+    def wait_event(self, e):
+        pass
+
+    def wait_stream(self, s):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+class _HostPreprocess:
+    """Stands in for DevicePreprocessor: same `batch` contract, computed with the host path."""
+
+    def __init__(self, size):
+        self.size = size
+
+    def batch(self, arrays, out, pool=None):
+        from PIL import Image
+        for j, a in enumerate(arrays):
+            out[j] = inf.preprocess_image(Image.fromarray(np.ascontiguousarray(a[..., :3])), self.size)
+        return out
+
+
+class _StubHandle:
+    done_event = None
+
+    def __init__(self, pair):
+        self._pair = pair
+
+    def result(self):
+        return self._pair
+
+
+class _StubModel:
+    """A forward whose outputs are a known function of the pixels, so that rows can be traced to their files."""
+    use_ambient = use_focal = use_exif = True
+    faithful_curiosity = False
+
+    @staticmethod
+    def values(x):
+        return x.mean(dim=(1, 2, 3))[:, None], torch.sigmoid(x.std(dim=(1, 2, 3)))[:, None]
+
+    def forward_async(self, x, exif):
+        assert exif["camera_idx"].shape[0] == x.shape[0]
+        return _StubHandle(self.values(x))
+
+    def synchronize(self):
+        pass
+
+
+def _stub_harness(size=(28, 28), batch_size=2):
+    h = inf.CognitiveAimInference.__new__(inf.CognitiveAimInference)
+    h.device, h.image_size, h.batch_size, h.render = torch.device("cpu"), size, batch_size, False
+    h.camera_to_id, h.config = {"unknown": 0}, {"cognitive_modules": []}
+    h.preprocess, h.model = _HostPreprocess(size), _StubModel()
+    return h
+
+
+def _fake_gpu_runtime():
+    """The loop's stream / event / pinned-memory calls without a GPU: ordering is trivially sequential on a CPU."""
+    import contextlib
+    torch.cuda.Stream = lambda *a, **k: _FakeStream()
+    torch.cuda.Event = lambda *a, **k: _FakeEvent()
+    torch.cuda.stream = lambda s: contextlib.nullcontext()
+    torch.cuda.current_stream = lambda *a, **k: _FakeStream()
+    torch.cuda.set_device = lambda d: None
+    torch.Tensor.pin_memory = lambda self, *a, **k: self
+
+
+def _run_worker(rank, world, port, files, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _fake_gpu_runtime()
+    res = _stub_harness().predict_batch(files)
+    q.put((rank, [(r[0], r[1], r[2].get("error"), r[2].get("rank"), r[2].get("image_path")) for r in res]))
+    dist.destroy_process_group()
+
+
+def test_batch_loop_on_two_ranks_with_a_failing_file(tmp_path):
+    """CognitiveAimInference._run under torch.distributed (world size 2): each rank decodes, batches and 'forwards'
+    only its contiguous shard (several chunks each, so input slots are reused), the file that cannot be read costs
+    only its own row, and after ONE all-gather every rank holds every image's row in request order."""
+    import torch.multiprocessing as mp
+    from PIL import Image
+    rng = np.random.default_rng(17)
+    files = []
+    for i in range(13):
+        p = str(tmp_path / f"f{i:02d}.png")
+        Image.fromarray(rng.integers(0, 256, size=(40 + i, 50 + 2 * i, 3), dtype=np.uint8), "RGB").save(p)
+        files.append(p)
+    bad = 9                                            # lies in rank 1's shard (rows 7..12)
+    files[bad] = str(tmp_path / "not_there.png")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_run_worker, args=(r, 2, port, files, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = {}
+    for i, f in enumerate(files):
+        if i != bad:
+            d, c = _StubModel.values(inf.preprocess_image(Image.open(f), (28, 28))[None])
+            want[i] = (float(d), float(c))
+    assert inf.shard_range(13, 0, 2) == (0, 7)
+    for rank in (0, 1):
+        rows = got[rank]
+        assert len(rows) == 13
+        for i, (d, c, err, where, path) in enumerate(rows):
+            mine = (i < 7) == (rank == 0)
+            if i == bad:
+                assert d is None and err and (("remote" in err) != mine)
+                continue
+            assert abs(d - want[i][0]) <= 1e-6 and abs(c - want[i][1]) <= 1e-6, (rank, i)
+            assert path == files[i] and (where == "remote") != mine
+
+
+def test_batch_loop_single_rank_many_chunks_and_stop_on_failure(tmp_path, monkeypatch):
+    """The same loop on one rank: nine chunks through four slots give every file its own row; a forward that raises
+    ends the producer thread instead of leaving it parked on the hand-over queue."""
+    import threading
+    from PIL import Image
+    _fake = {k: getattr(torch.cuda, k) for k in ("Stream", "Event", "stream", "current_stream", "set_device")}
+    pin = torch.Tensor.pin_memory
+    try:
+        _fake_gpu_runtime()
+        rng = np.random.default_rng(4)
+        files = []
+        for i in range(9):
+            p = str(tmp_path / f"g{i}.png")
+            Image.fromarray(rng.integers(0, 256, size=(30 + i, 33, 3), dtype=np.uint8), "RGB").save(p)
+            files.append(p)
+        h = _stub_harness(batch_size=1)
+        res = h.predict_batch(files)
+        for f, r in zip(files, res):
+            d, c = _StubModel.values(inf.preprocess_image(Image.open(f), (28, 28))[None])
+            assert abs(r[0] - float(d)) <= 1e-6 and abs(r[1] - float(c)) <= 1e-6 and r[2]["image_path"] == f
+
+        def boom(x, exif):
+            raise RuntimeError("forward failed")
+        h.model.forward_async = boom
+        with pytest.raises(RuntimeError, match="forward failed"):
+            h.predict_batch(files)
+        assert not [t for t in threading.enumerate() if t.name == "cogaim-producer" and t.is_alive()]
+    finally:
+        for k, v in _fake.items():
+            setattr(torch.cuda, k, v)
+        torch.Tensor.pin_memory = pin
+
+
+def test_host_thread_budget_divides_the_cores_between_local_ranks(monkeypatch):
+    monkeypatch.setenv("COGAIM_HOST_THREADS", "16")
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    assert inf.host_thread_budget() == (16, 8)
+    monkeypatch.delenv("COGAIM_HOST_THREADS")
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(16)), raising=False)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert inf.host_thread_budget() == (2, 1)           # 16 cores, 8 ranks: two decoders and one packer each
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    assert inf.host_thread_budget() == (16, 8)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(128)), raising=False)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert inf.host_thread_budget() == (16, 8)
+
+
+def test_weight_signature_sees_in_place_edits_and_repointed_storage():
+    """The packed 16-bit copies are keyed on every parameter's (version counter, address): in-place arithmetic on
+    the parameter, nn.init on it, a write through a state_dict() alias and ``p.data = t`` all change the key.  Only
+    in-place writes through ``p.data`` (a view with a version counter of its own) need refresh_weights()."""
+    m = CognitiveAimModel(_TINY, {"num_cameras": 71})
+    s0 = m._signature()
+    assert m._signature() == s0
+    p = m.backbone.encoder.layer[0].mlp.fc1.weight if hasattr(m.backbone.encoder.layer, "__getitem__") else \
+        getattr(m.backbone.encoder.layer, "0").mlp.fc1.weight
+    with torch.no_grad():
+        p.mul_(1.5)
+    s1 = m._signature()
+    assert s1 != s0
+    p.data.mul_(2.0)                                   # invisible to torch's version counter ...
+    assert m._signature() == s1
+    m.refresh_weights()                                # ... so the caller says so
+    s1 = m._signature()
+    assert s1 != s0
+    torch.nn.init.normal_(p, 0, 0.02)
+    s2 = m._signature()
+    assert s2 != s1
+    m.state_dict()["decision_head.0.bias"].add_(1.0)
+    s3 = m._signature()
+    assert s3 != s2
+    p.data = p.data.clone()
+    assert m._signature() != s3
+
+
+def test_host_side_error_fallbacks_route_like_the_reference(monkeypatch):
+    """The routing of the reference's blanket handlers (src/model.py:1050-1056, :1237-1240), checked without a GPU by
+    recording what the device part would be asked to do: a bad EXIF dict -> one pass with EXIF dropped and the
+    all-zero backup features; an unusable guidance tensor -> the standard forward; ``strict_errors`` -> raise."""
+    m = CognitiveAimModel(_TINY, {"num_cameras": 71})
+    seen = []
+
+    def core(images, exif_data, curiosity_calls=0, zero_features=False):
+        seen.append(("core", exif_data, zero_features))
+        B = images.shape[0]
+        return torch.zeros(B, 1), torch.zeros(B, 1), torch.zeros(B, 4), torch.zeros(B, 192)
+    monkeypatch.setattr(m, "_forward_core", core)
+    x = torch.zeros(2, 3, 28, 28)
+    good = {"camera_idx": torch.zeros(2, dtype=torch.long), "focal_length": torch.ones(2), "aperture": torch.ones(2),
+            "iso": torch.ones(2)}
+    m(x, good)
+    assert seen[-1] == ("core", good, False)
+    for bad in ({k: v for k, v in good.items() if k != "aperture"}, dict(good, iso=torch.ones(3)),
+                dict(good, focal_length=[1.0, 2.0]), "not a dict"):
+        m(x, bad)
+        assert seen[-1] == ("core", None, True), bad
+    calls = len(seen)
+    out = m.forward_with_guidance(x, good, torch.rand(10))          # 10 values cannot be laid out on a 2 x 2 grid
+    assert len(seen) == calls + 1 and seen[-1] == ("core", good, False) and len(out) == 2
+    strict = CognitiveAimModel(dict(_TINY, strict_errors=True), {"num_cameras": 71})
+    monkeypatch.setattr(strict, "_forward_core", core)
+    with pytest.raises(KeyError):
+        strict(x, {k: v for k, v in good.items() if k != "aperture"})
+    with pytest.raises(ValueError):
+        strict(x, dict(good, iso=torch.ones(3)))
+    with pytest.raises(Exception):
+        strict.forward_with_guidance(x, good, torch.rand(10))
+    assert float(m.get_features_aligned(x, "not a dict").abs().max()) == 0.0
