@@ -21,7 +21,6 @@ SIGNATURES = {
     "cogaim_preprocess_rgb8": [P, I, I, LL, I, P, P, I, P, P, I, P, P, P, I, I, P],
     "cogaim_preprocess_rgb8_batch": [P, I, I, P, I, I, P],
     "cogaim_gemm_workspace_bytes": [],
-    "cogaim_set_gemm_algo": [I],
     "cogaim_im2col": [P, P, I, I, I, I, I, I, P],
     "cogaim_gemm_patch_embed": [P, P, P, P, P, I, I, I, I, I, P, LL, P],
     "cogaim_cls_row": [P, P, P, I, I, I, P],
@@ -49,15 +48,50 @@ SIGNATURES = {
     "cogaim_guided_attention": [P, P, P, I, I, F, F, P],
     "cogaim_guided_attention_multi": [P, P, P, I, I, I, F, F, P],
     "cogaim_weighted_tokens_multi": [P, LL, P, P, P, I, I, I, I, P],
-    "cogaim_linear_f32": [P, I, P, P, P, P, I, I, I, I, I, P],
+    "cogaim_linear_f32": [P, I, P, P, P, P, P, I, I, I, I, I, P],
     "cogaim_exif_prep": [P, P, P, P, P, I, I, P, I, P, I, P, P],
     "cogaim_heads": [P, I, P, P, P, P, P, P, P, P, I, P],
+    "cogaim_mlp_chain": [P, I, P],
+    "cogaim_fusion_heads": [P, I, I, P, P, I, P, P, P, P, P, P, P, P, P, I, P],
+    "cogaim_export_outputs": [P, P, P, I, P, I, P, P, P, P, P, P, I, I, P],
+    "cogaim_host_pointer_ok": [P],
     "cogaim_heatmap_postprocess": [P, P, I, I, I, P],
     "cogaim_curiosity_sample": [P, P, P, P, P, LL, P, P, I, I, I, P],
     "cogaim_curiosity_finish": [P, P, LL, P, P, P, P, P, P, P, P, P, I, I, I, P],
 }
 
-_NO_STATUS = {"cogaim_version", "cogaim_gemm_workspace_bytes", "cogaim_focal_colsum_rows", "cogaim_weighted_tokens_rows",
+
+
+class MlpLayer(C.Structure):
+    """cogaim_mlp_layer of include/cogaim.h."""
+    _fields_ = [("W", P), ("b", P), ("b2", P), ("K", I), ("O", I), ("act", I), ("in_off", I), ("out_off", I), ("reserved", I)]
+
+
+class MlpChainDesc(C.Structure):
+    """cogaim_mlp_chain_desc of include/cogaim.h."""
+    _fields_ = [("layer", MlpLayer * 8), ("n_layers", I), ("in0_len", I), ("in0_off", I), ("in0_parts", I),
+                ("in0", P), ("in0_ld", LL), ("in0_part_stride", LL),
+                ("in1", P), ("in1_ld", LL), ("in1_len", I), ("in1_off", I),
+                ("scale", P), ("out", P), ("out_ld", LL), ("out_len", I), ("out_off", I)]
+
+
+def mlp_chain(layers, in0, in0_ld, in0_len, out, out_ld, out_len, out_off, B, in0_off=0, in0_parts=1, in0_part_stride=0,
+              in1=None, in1_ld=0, in1_len=0, in1_off=0, scale=None):
+    """cogaim_mlp_chain: `layers` = [(W ptr, b ptr, b2 ptr, K, O, act, in_off, out_off), ...] (at most eight)."""
+    d = MlpChainDesc()
+    for i, (W, b, b2, K, O, act, io, oo) in enumerate(layers):
+        d.layer[i] = MlpLayer(W, b, b2, K, O, act, io, oo, 0)
+    d.n_layers, d.in0_len, d.in0_off, d.in0_parts = len(layers), in0_len, in0_off, in0_parts
+    d.in0, d.in0_ld, d.in0_part_stride = in0, in0_ld, in0_part_stride
+    d.in1, d.in1_ld, d.in1_len, d.in1_off = in1, in1_ld, in1_len, in1_off
+    d.scale, d.out, d.out_ld, d.out_len, d.out_off = scale, out, out_ld, out_len, out_off
+    return call("cogaim_mlp_chain", C.byref(d), B, stream_ptr())
+
+
+# exported by -DCOGAIM_TOOLS builds only (tools/wt_build.sh): bound when the loaded library has them
+OPTIONAL = {"cogaim_set_gemm_algo": [I]}
+
+_NO_STATUS = {"cogaim_version", "cogaim_host_pointer_ok", "cogaim_gemm_workspace_bytes", "cogaim_focal_colsum_rows", "cogaim_weighted_tokens_rows",
               "cogaim_focal_rowstats_parts", "cogaim_focal_scores_colsum_blocks"}
 _lib = None
 
@@ -82,6 +116,10 @@ def lib() -> C.PyDLL:
             fn = getattr(handle, name)
             fn.argtypes = args
             fn.restype = LL if name == "cogaim_gemm_workspace_bytes" else I
+        for name, args in OPTIONAL.items():
+            if hasattr(handle, name):
+                fn = getattr(handle, name)
+                fn.argtypes, fn.restype = args, I
         _lib = handle
     return _lib
 

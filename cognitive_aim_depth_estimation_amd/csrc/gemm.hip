@@ -514,7 +514,8 @@ int g_gemm_band = -1;       // tile numbering of the persistent kernel: -1 = cho
 
 int g_gemm_diag = 0;   // timing-only diagnostic variant (wrong results): reachable only in -DCOGAIM_TOOLS builds
 int g_gemm_algo = 2;   // 0: 128x128 kernel everywhere; 1: 256x256 ping-pong kernel, one tile per workgroup;
-                       // 2: persistent 256x256 ping-pong kernel (large problems only for 1 and 2)
+                       // 2: persistent 256x256 ping-pong kernel (large problems only for 1 and 2); changed only
+                       // by -DCOGAIM_TOOLS builds
 
 template <class T, class Epi, bool SWAP>
 int launch(const GemmShape& g, const Epi& epi, int batch, hipStream_t st, bool ragged_n = false,
@@ -633,8 +634,6 @@ int cogaim_gemm_patch_embed(const void* cols, const void* W, const float* bias, 
                     (launch<_Float16, EpiPatchEmbed, true>(g, e, 1, (hipStream_t)stream, false, workspace, workspace_bytes)));
 }
 
-// Tuning knob: 0 = 128x128 kernel for every problem; 1 = 256x256 kernel, one tile per workgroup;
-// 2 (default) = persistent 256x256 kernel.  1 and 2 apply to large problems only.
 #ifdef COGAIM_STAMPS
 int cogaim_debug_stamps(void* dst) {
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamp_buf), sizeof(long long) * 256 * 12 * 4) == hipSuccess ? 0 : -1;
@@ -643,18 +642,21 @@ int cogaim_debug_clock(void* dst) {
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_clock_buf), sizeof(long long) * 4 * 256 * 4) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef COGAIM_TOOLS
+// Experiment knobs of tools/gemm_bench.py; process-wide and unsynchronised, which is why the shipped library does
+// not export them.  0 = 128x128 kernel for every problem; 1 = 256x256 kernel, one tile per workgroup; 2 (default) =
+// persistent 256x256 kernel (1 and 2 apply to large problems only); the larger codes set the other g_gemm_* values.
 int cogaim_set_gemm_algo(int algo) {
-#ifdef COGAIM_TOOLS   // experiment knobs of tools/gemm_bench.py; the shipped library accepts 0, 1 and 2 only
   if (algo >= 1000) { g_gemm_slice_cap = algo - 1000; return COGAIM_OK; }
   if (algo == 300 || algo == 301) { g_gemm_quads = algo - 300; return COGAIM_OK; }
   if (algo >= 200) { g_gemm_band = algo == 299 ? -1 : algo - 200; return COGAIM_OK; }
   if (algo >= 100) { g_gemm_diag = 1; g_gemm_algo = algo - 100; return COGAIM_OK; }
-#endif
   if (algo < 0 || algo > 2) return COGAIM_EINVAL;
   g_gemm_algo = algo;
   g_gemm_diag = 0;
   return COGAIM_OK;
 }
+#endif
 
 // Bytes of split-K workspace that let every GEMM entry point remove its partial last round of tiles.
 long long cogaim_gemm_workspace_bytes() { return 256LL * 32 * 512 * 16; }   // 256 partial tiles of 256 KiB

@@ -3,14 +3,15 @@
 // :482-519 EXIF prior, :908-941 fusion / decision / confidence heads).
 // Batch-many-rows x few-hundred-columns: GEMV class, one wave per output.
 #include "common.h"
+#include "../../include/cogaim.h"
 
 namespace {
 
-// out[b*ldo + o] = act(x[b*ldx + :K] . W[o*K + :K] + bias[o] * (bias_scale ? bias_scale[b] : 1))
+// out[b*ldo + o] = act(x[b*ldx + :K] . W[o*K + :K] + bias[o] + bias2[o] * bias2_scale[b])
 __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ x, int ldx,
                                                          const float* __restrict__ W, const float* __restrict__ bias,
-                                                         const float* __restrict__ bias_scale, float* __restrict__ out,
-                                                         int ldo, int B, int O, int K, int act) {
+                                                         const float* __restrict__ bias2, const float* __restrict__ bias2_scale,
+                                                         float* __restrict__ out, int ldo, int B, int O, int K, int act) {
   const int lane = threadIdx.x & 63;
   const long long wid = blockIdx.x * 4LL + (threadIdx.x >> 6);
   if (wid >= (long long)B * O) return;
@@ -29,9 +30,8 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
   }
   acc = wave_sum(acc);
   if (lane == 0) {
-    float bv = bias ? bias[o] : 0.f;
-    if (bias_scale) bv *= bias_scale[b];
-    float y = acc + bv;
+    float y = acc + (bias ? bias[o] : 0.f);
+    if (bias2) y += bias2[o] * (bias2_scale ? bias2_scale[b] : 1.0f);
     if (act == 1) y = y < 0.f ? 0.f : y;      // ReLU that keeps a NaN a NaN, as torch's does (fmaxf would drop it)
     out[(size_t)b * ldo + o] = y;
   }
@@ -80,6 +80,150 @@ __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ fu
     const float zc = (hc < 0.f ? 0.f : hc) * w2[0] + b2[0];      // NaN-keeping ReLU
     conf[b] = 1.0f / (1.0f + expf(-zc));
   }
+}
+
+// ---- several small layers in ONE launch ---------------------------------------------------------------------------
+// One 1024-thread workgroup per image walks up to eight Linear layers whose activations stay in LDS (4096 floats):
+//   out_l[o] = act(W_l[o, :K] . in_l + b_l[o] + b2_l[o] * scale[image])
+// `in_l` / `out_l` are offsets into the LDS array, so a layer can read the concatenation of an input vector and an
+// earlier layer's output (EXIF prior: embedding | encoder output).  The first input may be given as `parts` partial
+// vectors that are summed while they are loaded (pairs of running sums, parts ascending: the order of
+// reduce_partials_kernel).  A wave owns four outputs at a time; the lanes stride over K.
+constexpr int MLP_LDS = 4096;
+constexpr int MLP_MAX_LAYERS = 8;
+struct MlpLayerDev { const float* W; const float* b; const float* b2; int K, O, act, in_off, out_off, pad; };
+struct MlpChainDev {
+  MlpLayerDev layer[MLP_MAX_LAYERS];
+  int n_layers, in0_len, in0_off, in0_parts;
+  const float* in0; long long in0_ld, in0_part_stride;
+  const float* in1; long long in1_ld; int in1_len, in1_off;
+  const float* scale;
+  float* out; long long out_ld; int out_len, out_off;
+};
+
+__global__ __launch_bounds__(1024) void mlp_chain_kernel(MlpChainDev d) {
+  __shared__ __attribute__((aligned(16))) float buf[MLP_LDS];
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    const float* p = d.in0 + (size_t)img * d.in0_ld;
+    for (int i = tid; i < d.in0_len; i += 1024) {
+      float s0 = 0.f, s1 = 0.f;
+      int k = 0;
+      for (; k + 1 < d.in0_parts; k += 2) { s0 += p[(size_t)k * d.in0_part_stride + i]; s1 += p[(size_t)(k + 1) * d.in0_part_stride + i]; }
+      if (k < d.in0_parts) s0 += p[(size_t)k * d.in0_part_stride + i];
+      buf[d.in0_off + i] = d.in0_parts == 1 ? p[i] : s0 + s1;
+    }
+    if (d.in1)
+      for (int i = tid; i < d.in1_len; i += 1024) buf[d.in1_off + i] = d.in1[(size_t)img * d.in1_ld + i];
+  }
+  __syncthreads();
+  const float sc = d.scale ? d.scale[img] : 1.0f;
+#pragma unroll 1
+  for (int l = 0; l < d.n_layers; ++l) {
+    const MlpLayerDev L = d.layer[l];
+    const float* in = buf + L.in_off;
+    const bool vec = ((L.K | L.in_off) & 3) == 0 && (reinterpret_cast<uintptr_t>(L.W) & 15) == 0;
+#pragma unroll 1
+    for (int o0 = wave * 4; o0 < L.O; o0 += 64) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = L.W + (size_t)min(o0 + j, L.O - 1) * L.K;
+      if (vec) {
+        for (int k = lane * 4; k < L.K; k += 256) {
+          const float4 a = *reinterpret_cast<const float4*>(in + k);
+          float4 ww[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ww[j] = *reinterpret_cast<const float4*>(w[j] + k);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += (a.x * ww[j].x + a.y * ww[j].y) + (a.z * ww[j].z + a.w * ww[j].w);
+        }
+      } else {
+        for (int k = lane; k < L.K; k += 64) {
+          const float a = in[k];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += a * w[j][k];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = wave_sum(acc[j]);
+      if (lane < 4 && o0 + lane < L.O) {
+        const int o = o0 + lane;
+        float y = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+        if (L.b) y += L.b[o];
+        if (L.b2) y += L.b2[o] * sc;
+        if (L.act == 1) y = y < 0.f ? 0.f : y;          // ReLU that keeps a NaN a NaN, as torch's does
+        buf[L.out_off + o] = y;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < d.out_len; i += 1024) d.out[(size_t)img * d.out_ld + i] = buf[d.out_off + i];
+}
+
+// fused[b] = relu(Wf cat[b] + bf) (src/model.py:908-912, 1045), then the two heads (:925-941, 1120-1123) from it:
+// one workgroup per image, the fused row stays in LDS.
+constexpr int FH_MAX = 1024;
+__global__ __launch_bounds__(256) void fusion_heads_kernel(const float* __restrict__ cat, int ldcat, int K,
+                                                           const float* __restrict__ wf, const float* __restrict__ bf, int F,
+                                                           const float* __restrict__ wd, const float* __restrict__ bd,
+                                                           const float* __restrict__ wc, const float* __restrict__ bc,
+                                                           const float* __restrict__ w2, const float* __restrict__ b2,
+                                                           float* __restrict__ fused, float* __restrict__ depth,
+                                                           float* __restrict__ conf) {
+  __shared__ float xin[FH_MAX], f[FH_MAX];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < K; i += 256) xin[i] = cat[(size_t)b * ldcat + i];
+  __syncthreads();
+  for (int o = wave; o < F; o += 4) {
+    const float* w = wf + (size_t)o * K;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc += xin[k] * w[k];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float y = acc + bf[o];
+      const float r = y < 0.f ? 0.f : y;                // NaN-keeping ReLU
+      f[o] = r;
+      fused[(size_t)b * F + o] = r;
+    }
+  }
+  __syncthreads();
+  if (wave < 2) {
+    const float* w = wave == 0 ? wd : wc;
+    float acc = 0.f;
+    for (int k = lane; k < F; k += 64) acc += f[k] * w[k];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      if (wave == 0) {
+        const float zd = acc + bd[0];
+        depth[b] = zd > 20.f ? zd : log1pf(expf(zd));
+      } else {
+        const float hc = acc + bc[0];
+        const float zc = (hc < 0.f ? 0.f : hc) * w2[0] + b2[0];
+        conf[b] = 1.0f / (1.0f + expf(-zc));
+      }
+    }
+  }
+}
+
+// Results of one forward out of the (fixed) workspace into the caller's fresh tensors, one launch: depth, confidence,
+// fused features, attention rows, and the device-side condition words into a host-mapped snapshot.
+__global__ __launch_bounds__(256) void export_outputs_kernel(const float* __restrict__ depth_src, const float* __restrict__ conf_src,
+                                                             const float* __restrict__ fused_src, int F,
+                                                             const float* __restrict__ attn_src, int N,
+                                                             float* __restrict__ depth, float* __restrict__ conf,
+                                                             float* __restrict__ fused, float* __restrict__ attn,
+                                                             const int* __restrict__ flags, int* __restrict__ flags_host,
+                                                             int n_flags, int B) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b == B) {
+    if (flags_host)
+      for (int i = tid; i < n_flags; i += 256) flags_host[i] = flags[i];
+    return;
+  }
+  if (tid == 0) { depth[b] = depth_src[b]; conf[b] = conf_src[b]; }
+  if (fused) for (int i = tid; i < F; i += 256) fused[(size_t)b * F + i] = fused_src[(size_t)b * F + i];
+  if (attn) for (int i = tid; i < N; i += 256) attn[(size_t)b * N + i] = attn_src[(size_t)b * N + i];
 }
 
 
@@ -221,13 +365,74 @@ int cogaim_curiosity_finish(const float* rec, const float* cls, long long ld_cls
 }
 
 
-// act: 0 identity, 1 ReLU.  bias / bias_scale may be NULL.
-int cogaim_linear_f32(const float* x, int ldx, const float* W, const float* bias, const float* bias_scale, float* out,
-                      int ldo, int B, int O, int K, int act, void* stream) {
+// act: 0 identity, 1 ReLU.  bias / bias2 / bias2_scale may be NULL.
+int cogaim_linear_f32(const float* x, int ldx, const float* W, const float* bias, const float* bias2,
+                      const float* bias2_scale, float* out, int ldo, int B, int O, int K, int act, void* stream) {
   if (B <= 0 || O <= 0 || K <= 0 || ldx < K || (act != 0 && act != 1)) return COGAIM_EINVAL;
   const long long waves = (long long)B * O;
   hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, W,
-                     bias, bias_scale, out, ldo, B, O, K, act);
+                     bias, bias2, bias2_scale, out, ldo, B, O, K, act);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+// Up to eight small Linear layers per image in one launch (see mlp_chain_kernel).  `desc` is read on the host.
+int cogaim_mlp_chain(const cogaim_mlp_chain_desc* desc, int B, void* stream) {
+  if (!desc || B <= 0 || desc->n_layers < 1 || desc->n_layers > MLP_MAX_LAYERS || !desc->in0 || !desc->out) return COGAIM_EINVAL;
+  auto region_ok = [](long long off, long long len) { return off >= 0 && len >= 0 && off + len <= MLP_LDS; };
+  if (!region_ok(desc->in0_off, desc->in0_len) || desc->in0_len < 1 || desc->in0_parts < 1 ||
+      (desc->in1 && !region_ok(desc->in1_off, desc->in1_len)) || !region_ok(desc->out_off, desc->out_len) ||
+      desc->out_len < 1 || desc->out_ld < desc->out_len || desc->in0_ld < 0)
+    return COGAIM_EINVAL;
+  MlpChainDev d{};
+  for (int l = 0; l < desc->n_layers; ++l) {
+    const cogaim_mlp_layer& L = desc->layer[l];
+    if (!L.W || L.K < 1 || L.O < 1 || (L.act != 0 && L.act != 1) || !region_ok(L.in_off, L.K) || !region_ok(L.out_off, L.O))
+      return COGAIM_EINVAL;
+    // a layer must not overwrite what it is still reading
+    if (L.out_off < L.in_off + L.K && L.in_off < L.out_off + L.O) return COGAIM_EINVAL;
+    d.layer[l] = MlpLayerDev{L.W, L.b, L.b2, L.K, L.O, L.act, L.in_off, L.out_off, 0};
+  }
+  d.n_layers = desc->n_layers;
+  d.in0 = desc->in0; d.in0_ld = desc->in0_ld; d.in0_part_stride = desc->in0_part_stride;
+  d.in0_len = desc->in0_len; d.in0_off = desc->in0_off; d.in0_parts = desc->in0_parts;
+  d.in1 = desc->in1; d.in1_ld = desc->in1_ld; d.in1_len = desc->in1 ? desc->in1_len : 0; d.in1_off = desc->in1_off;
+  d.scale = desc->scale;
+  d.out = desc->out; d.out_ld = desc->out_ld; d.out_len = desc->out_len; d.out_off = desc->out_off;
+  hipLaunchKernelGGL(mlp_chain_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, d);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+// fused [B,F] = relu(Wf cat + bf); depth[b] = softplus(wd . fused + bd); conf[b] = sigmoid(w2 relu(wc . fused + bc) + b2)
+int cogaim_fusion_heads(const float* cat, int ldcat, int K, const float* wf, const float* bf, int F, const float* wd,
+                        const float* bd, const float* wc, const float* bc, const float* w2, const float* b2, float* fused,
+                        float* depth, float* conf, int B, void* stream) {
+  if (B <= 0 || K <= 0 || K > FH_MAX || F <= 0 || F > FH_MAX || ldcat < K || !cat || !wf || !bf || !fused || !depth || !conf)
+    return COGAIM_EINVAL;
+  hipLaunchKernelGGL(fusion_heads_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, cat, ldcat, K, wf, bf, F, wd, bd, wc,
+                     bc, w2, b2, fused, depth, conf);
+  return COGAIM_LAUNCH_CHECK();
+}
+
+// 0 when a kernel may store through `host_ptr` (page-locked, mapped host memory whose device address equals its host
+// address), else -22.  Lets a caller decide once whether cogaim_export_outputs may be given a host snapshot buffer.
+int cogaim_host_pointer_ok(void* host_ptr) {
+  if (!host_ptr) return COGAIM_EINVAL;
+  void* dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, host_ptr, 0) != hipSuccess) { (void)hipGetLastError(); return COGAIM_EINVAL; }
+  return dev == host_ptr ? COGAIM_OK : COGAIM_EINVAL;
+}
+
+// One launch that copies a forward's results out of fixed workspace buffers: depth / conf [B], fused [B,F] (dst NULL:
+// skipped), attention [B,N] (dst NULL: skipped) and n_flags condition words into flags_host (NULL: skipped; must have
+// passed cogaim_host_pointer_ok).
+int cogaim_export_outputs(const float* depth_src, const float* conf_src, const float* fused_src, int F,
+                          const float* attn_src, int N, float* depth, float* conf, float* fused, float* attn,
+                          const int* flags, int* flags_host, int n_flags, int B, void* stream) {
+  if (B <= 0 || !depth_src || !conf_src || !depth || !conf || (fused && (!fused_src || F <= 0)) ||
+      (attn && (!attn_src || N <= 0)) || (flags_host && (!flags || n_flags <= 0)))
+    return COGAIM_EINVAL;
+  hipLaunchKernelGGL(export_outputs_kernel, dim3(B + 1), dim3(256), 0, (hipStream_t)stream, depth_src, conf_src, fused_src,
+                     F, attn_src, N, depth, conf, fused, attn, flags, flags_host, n_flags, B);
   return COGAIM_LAUNCH_CHECK();
 }
 
@@ -258,6 +463,6 @@ int cogaim_heatmap_postprocess(const float* attn, float* out, int B, int N, int 
   return COGAIM_LAUNCH_CHECK();
 }
 
-int cogaim_version() { return 3; }
+int cogaim_version() { return 4; }
 
 }  // extern "C"

@@ -34,7 +34,7 @@ import torch
 import torch.nn as nn
 
 from . import tables
-from ._lib import call, ptr, stream_ptr
+from ._lib import call, mlp_chain, ptr, stream_ptr
 
 LOG2E = 1.4426950408889634
 _DTYPES = {"bf16": (0, torch.bfloat16), "fp16": (1, torch.float16)}
@@ -422,9 +422,15 @@ class CognitiveAimModel(nn.Module):
             # in), and the scores are Y X^T against the tokens themselves (src/model.py:192-200).
             wq, wk = sd[p + "query_proj.weight"].float(), sd[p + "key_proj.weight"].float()
             ss = LOG2E / math.sqrt(wq.shape[1] // 8)   # FocalStream.scale = sqrt(patch_dim // num_heads), heads = 8
+            # The value projection is followed by the first projection layer with nothing in between (:194, :308-311):
+            #   P0 (Wv w + bv s) + b0 = (P0 Wv) w + (P0 bv) s + b0   (s = sum of the column weights),
+            # so the [256, D] product is formed once here (in fp64, rounded once) and the per-image chain is two layers.
+            p0 = sd[p + "projection.0.weight"].double()
             focal.append({
                 "wm": ((wk.t() @ wq) * ss).to(tdt).contiguous(),
                 "bv": ((sd[p + "query_proj.bias"].float() @ wk) * ss).contiguous(),
+                "m1": (p0 @ sd[p + "value_proj.weight"].double()).float().contiguous(),
+                "c1": (p0 @ sd[p + "value_proj.bias"].double()).float().contiguous(),
             })
         pk["focal"] = focal
         pk["f32"] = {k: v.float().contiguous() for k, v in sd.items()
@@ -514,27 +520,31 @@ class CognitiveAimModel(nn.Module):
             "flag_ring": [{"host": torch.zeros(_FLAG_WORDS, dtype=torch.int32).pin_memory(), "event": torch.cuda.Event(),
                            "pending": False} for _ in range(_FLAG_SNAPSHOTS)],
             "flag_next": 0,
+            "flags_mapped": False,
             "u": torch.empty(B, N, **f32), "usum": torch.empty(B, **f32),
             "wt": torch.empty(B, D, **f32), "w": torch.empty(B, D, **f32),
             "wtpart": torch.empty(B * ((N + call("cogaim_weighted_tokens_rows") - 1)
                                        // call("cogaim_weighted_tokens_rows")) * D, **f32),
-            "t256": torch.empty(B, 256, **f32), "t128": torch.empty(B, 128, **f32), "t64": torch.empty(B, 64, **f32),
+            "t256": torch.empty(B, 256 * max(1, self.num_iterations), **f32), "a256": torch.empty(B, 256, **f32), "t128": torch.empty(B, 128, **f32), "t64": torch.empty(B, 64, **f32),
             "feats": torch.empty(B, 64 * max(1, self.num_iterations), **f32),
             "exf": torch.empty(B, 128, **f32), "cont": torch.empty(B, 3, **f32),
             "cat": torch.zeros(B, 192, **f32), "fused": torch.empty(B, 192, **f32),
             "guided": torch.empty(B, N, **f32), "out": torch.empty(2, B, **f32),
             "pw": torch.empty(64, D, **f32), "pb": torch.empty(64, **f32),
         }
+        # may a kernel store the flag words straight into the pinned snapshots?  (page-locked memory is mapped into the
+        # device's address space at its host address on this platform; checked, not assumed)
+        ws["flags_mapped"] = all(call("cogaim_host_pointer_ok", sl["host"].data_ptr()) == 0 for sl in ws["flag_ring"])
         self._ws[key] = ws
         return ws
 
     # ------------------------------------------------------------------ kernels
-    def _linear(self, x, ldx, wkey, out, ldo, B, act=0, bias_scale=None, W=None, bias=None):
+    def _linear(self, x, ldx, wkey, out, ldo, B, act=0, W=None, bias=None, bias2=None, bias2_scale=None):
         f = self._packed["f32"]
         W = f[wkey + ".weight"] if W is None else W
         bias = f[wkey + ".bias"] if bias is None else bias
         O, K = W.shape
-        call("cogaim_linear_f32", x, ldx, ptr(W), ptr(bias), ptr(bias_scale), out, ldo, B, O, K, act, stream_ptr())
+        call("cogaim_linear_f32", x, ldx, ptr(W), ptr(bias), ptr(bias2), ptr(bias2_scale), out, ldo, B, O, K, act, stream_ptr())
 
     def _backbone(self, images: Optional[torch.Tensor], shape: Tuple[int, int, int], ws: dict):
         """DINOv2 forward (hf:451-477) -> ws['tokens'] fp32 [B*T, D] (final LayerNorm applied).
@@ -609,18 +619,35 @@ class CognitiveAimModel(nn.Module):
                 call("cogaim_focal_weighted_colsum", S, ldS, N * ldS, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["attn"]), ptr(ws["part"]), B, N, st)
             call("cogaim_focal_reduce_u", ptr(ws["part"]), ptr(ws["u"]), ptr(ws["usum"]), B, N, ws["nblk"], st)
             call("cogaim_weighted_tokens", tok, tstride, s_in, ptr(pe), ptr(ws["u"]), ptr(ws["wt"]), ptr(ws["wtpart"]), B, N, D, st)
-            self._linear(ptr(ws["wt"]), D, pfx + "value_proj", ptr(ws["w"]), D, B, bias_scale=ws["usum"])
-            self._linear(ptr(ws["w"]), D, pfx + "projection.0", ptr(ws["t256"]), 256, B, act=1)
-            self._linear(ptr(ws["t256"]), 256, pfx + "projection.3", ws["feats"].data_ptr() + 64 * i * 4, 64 * I, B)
-        if self.use_iterative:
-            self._linear(ptr(ws["feats"]), 64 * I, "focal_stream.fusion.0", ptr(ws["t128"]), 128, B, act=1)
+            # value projection folded into projection.0 (see _pack) + ReLU: wide enough for one wave per output;
+            # projection.3 of every iteration runs inside the fusion chain (_focal_fused_into)
+            self._linear(ptr(ws["wt"]), D, pfx + "projection.0", ws["t256"].data_ptr() + 256 * i * 4, 256 * I, B, act=1,
+                         W=f["m1"], bias2=f["c1"], bias2_scale=ws["usum"])
         return ws["attn"]
 
     def _focal_fused_into(self, ws, B, col):
-        if self.use_iterative:      # fusion MLP over the concatenated per-iteration features (src/model.py:430)
-            self._linear(ptr(ws["t128"]), 128, "focal_stream.fusion.2", ws["cat"].data_ptr() + col * 4, 192, B)
-        else:                       # a bare FocalStream returns its projected features as they are (:311)
-            ws["cat"][:, col:col + 64].copy_(ws["feats"])
+        w32, I = self._packed["f32"], self.num_iterations
+        pfx = self._focal_prefixes()
+        cat = ws["cat"].data_ptr() + col * 4
+        # projection.3 of each iteration (256 -> 64, :82-87), then the fusion MLP over their concatenation (:342-346, 430)
+        # -- a bare FocalStream returns its projected features as they are (:311).  A chain holds at most eight layers:
+        # with more than six iterations each goes through a launch of its own that leaves its features in ws['feats'].
+        p3 = lambda i, src, dst: (ptr(w32[pfx[i] + "projection.3.weight"]), ptr(w32[pfx[i] + "projection.3.bias"]), None,
+                                  256, 64, 0, src, dst)
+        if not self.use_iterative:
+            mlp_chain([p3(0, 0, 1024)], ptr(ws["t256"]), 256, 256, cat, 192, 64, 1024, B)
+            return
+        fus = lambda src, mid, dst: [
+            (ptr(w32["focal_stream.fusion.0.weight"]), ptr(w32["focal_stream.fusion.0.bias"]), None, 64 * I, 128, 1, src, mid),
+            (ptr(w32["focal_stream.fusion.2.weight"]), ptr(w32["focal_stream.fusion.2.bias"]), None, 128, 64, 0, mid, dst)]
+        if I <= 6:       # t256 rows [B, 256 I] at 0; features at 2048; fusion hidden at 3072; result at 3584
+            mlp_chain([p3(i, 256 * i, 2048 + 64 * i) for i in range(I)] + fus(2048, 3072, 3584),
+                      ptr(ws["t256"]), 256 * I, 256 * I, cat, 192, 64, 3584, B)
+            return
+        for i in range(I):       # one launch per iteration (256 -> 64) ...
+            mlp_chain([p3(i, 0, 1024)], ws["t256"].data_ptr() + 256 * i * 4, 256 * I, 256,
+                      ws["feats"].data_ptr() + 64 * i * 4, 64 * I, 64, 1024, B)
+        mlp_chain(fus(0, 64 * I, 64 * I + 128), ptr(ws["feats"]), 64 * I, 64 * I, cat, 192, 64, 64 * I + 128, B)       # ... and the fusion
 
     def _check_fallback_flags(self, ws):
         """The reference switches to other attention summaries when the whole-batch variance of (column mean +
@@ -635,14 +662,46 @@ class CognitiveAimModel(nn.Module):
         leaves the GPU idle between two forwards until the host has issued the next one).  A caller that wants these
         conditions raised at a definite point calls ``model.synchronize()``.  An out-of-range camera index
         additionally makes that image's depth and confidence NaN, so its result cannot pass for a prediction."""
+        slot = self._flag_slot(ws)
+        slot["host"].copy_(ws["flags"], non_blocking=True)
+        self._flag_slot_filled(ws, slot)
+
+    def _flag_slot(self, ws):
+        """The snapshot the running call fills (examines the older ones first)."""
         self._examine_flags(ws, wait=False)
         slot = ws["flag_ring"][ws["flag_next"]]
         if slot["pending"]:                    # the host is a whole ring of forwards ahead of the device
             self._examine_flags(ws, wait=True)
-        slot["host"].copy_(ws["flags"], non_blocking=True)
+        return slot
+
+    def _flag_slot_filled(self, ws, slot):
         slot["event"].record()
         slot["pending"] = True
         ws["flag_next"] = (ws["flag_next"] + 1) % _FLAG_SNAPSHOTS
+
+    def _new_outputs(self, B, N, device):
+        """Fresh result tensors of one call, carved out of ONE allocation: depth [B,1], conf [B,1], fused [B,192],
+        attention [B,N] (None without a focal stream); each is contiguous."""
+        n_attn = N if self.use_focal else 0
+        flat = torch.empty(B * (2 + self.fusion_dim + n_attn), device=device, dtype=torch.float32)
+        depth, conf = flat[:B].view(B, 1), flat[B:2 * B].view(B, 1)
+        fused = flat[2 * B: 2 * B + B * self.fusion_dim].view(B, self.fusion_dim)
+        attn = flat[2 * B + B * self.fusion_dim:].view(B, N) if n_attn else None
+        return depth, conf, attn, fused
+
+    def _export(self, ws, B, dst, attn_src):
+        """Copies depth / confidence / fused features / attention out of the workspace into `dst` (the caller's
+        tensors) and takes the flag snapshot, in one launch (no per-tensor clones or copies)."""
+        depth, conf, attn, fused = dst
+        slot = self._flag_slot(ws)
+        mapped = ws["flags_mapped"]
+        out = ws["out"]
+        call("cogaim_export_outputs", out.data_ptr(), out.data_ptr() + B * 4, ptr(ws["fused"]), self.fusion_dim,
+             ptr(attn_src) if attn is not None else None, ws["N"], ptr(depth), ptr(conf), ptr(fused), ptr(attn),
+             ptr(ws["flags"]), slot["host"].data_ptr() if mapped else None, _FLAG_WORDS, B, stream_ptr())
+        if not mapped:
+            slot["host"].copy_(ws["flags"], non_blocking=True)
+        self._flag_slot_filled(ws, slot)
 
     def _examine_flags(self, ws, wait=True):
         """Oldest snapshot first; without `wait`, stops at the first one whose copy has not landed yet."""
@@ -688,9 +747,12 @@ class CognitiveAimModel(nn.Module):
     def _ambient(self, ws, B, col):
         T, D = ws["T"], self.feature_dim
         cls = ws["tokens"].data_ptr()                  # row b*T is the CLS token of image b
-        self._linear(cls, T * D, "ambient_stream.mlp.0", ptr(ws["t256"]), 256, B, act=1)
-        self._linear(ptr(ws["t256"]), 256, "ambient_stream.mlp.3", ptr(ws["t128"]), 128, B, act=1)
-        self._linear(ptr(ws["t128"]), 128, "ambient_stream.mlp.5", ws["cat"].data_ptr() + col * 4, 192, B)
+        w, a = self._packed["f32"], "ambient_stream.mlp."           # src/model.py:37-44, one launch
+        # the 768-wide first layer with one wave per output (fills the chip); the two narrow layers in one launch
+        self._linear(cls, T * D, a + "0", ptr(ws["a256"]), 256, B, act=1)
+        mlp_chain([(ptr(w[a + "3.weight"]), ptr(w[a + "3.bias"]), None, 256, 128, 1, 0, 1024),
+                   (ptr(w[a + "5.weight"]), ptr(w[a + "5.bias"]), None, 128, 64, 0, 1024, 2048)],
+                  ptr(ws["a256"]), 256, 256, ws["cat"].data_ptr() + col * 4, 192, 64, 2048, B)
 
     @staticmethod
     def _exif_check(exif_data, B: int):
@@ -730,16 +792,26 @@ class CognitiveAimModel(nn.Module):
              ptr(ws["cont"]), B, ws["flags"].data_ptr() + _FLAG_CAMERA * 4, stream_ptr())
 
     def _exif(self, ws, B, col):
-        self._linear(ptr(ws["cont"]), 3, "exif_prior.exif_encoder.0", ptr(ws["t64"]), 64, B, act=1)
-        self._linear(ptr(ws["t64"]), 64, "exif_prior.exif_encoder.2", ws["exf"].data_ptr() + 64 * 4, 128, B)
-        self._linear(ptr(ws["exf"]), 128, "exif_prior.fusion.0", ptr(ws["t256"]), 256, B, act=1)
-        self._linear(ptr(ws["t256"]), 256, "exif_prior.fusion.3", ws["cat"].data_ptr() + col * 4, 192, B)
+        # src/model.py:510-519 in one launch: encoder(3 -> 64 -> 64) on the continuous values, its output behind the
+        # camera embedding (columns 0..63 of ws['exf'], gathered by _exif_prep), fusion(128 -> 256 -> 64)
+        w, e = self._packed["f32"], "exif_prior."
+        mlp_chain([(ptr(w[e + "exif_encoder.0.weight"]), ptr(w[e + "exif_encoder.0.bias"]), None, 3, 64, 1, 0, 2048),
+                   (ptr(w[e + "exif_encoder.2.weight"]), ptr(w[e + "exif_encoder.2.bias"]), None, 64, 64, 0, 2048, 1024 + 64),
+                   (ptr(w[e + "fusion.0.weight"]), ptr(w[e + "fusion.0.bias"]), None, 128, 256, 1, 1024, 3072),
+                   (ptr(w[e + "fusion.3.weight"]), ptr(w[e + "fusion.3.bias"]), None, 256, 64, 0, 3072, 0)],
+                  ptr(ws["cont"]), 3, 3, ws["cat"].data_ptr() + col * 4, 192, 64, 0, B,
+                  in1=ptr(ws["exf"]), in1_ld=128, in1_len=64, in1_off=1024)
 
     def _heads(self, ws, B, fuse=True):
         f = self._packed["f32"]
-        if fuse:
-            self._linear(ptr(ws["cat"]), 192, "fusion.0", ptr(ws["fused"]), 192, B, act=1)
         out = ws["out"]
+        if fuse:        # fusion Linear(192, 192) + ReLU and both heads, one launch
+            call("cogaim_fusion_heads", ptr(ws["cat"]), 192, 192, ptr(f["fusion.0.weight"]), ptr(f["fusion.0.bias"]), 192,
+                 ptr(f["decision_head.0.weight"]), ptr(f["decision_head.0.bias"]),
+                 ptr(f["confidence_head.0.weight"]), ptr(f["confidence_head.0.bias"]),
+                 ptr(f["confidence_head.2.weight"]), ptr(f["confidence_head.2.bias"]),
+                 ptr(ws["fused"]), out.data_ptr(), out.data_ptr() + B * 4, B, stream_ptr())
+            return
         call("cogaim_heads", ptr(ws["fused"]), 192, ptr(f["decision_head.0.weight"]), ptr(f["decision_head.0.bias"]),
              ptr(f["confidence_head.0.weight"]), ptr(f["confidence_head.0.bias"]),
              ptr(f["confidence_head.2.weight"]), ptr(f["confidence_head.2.bias"]),
@@ -805,7 +877,8 @@ class CognitiveAimModel(nn.Module):
 
         def body():
             self._backbone(None, shape, ws)
-            ws["cat"].zero_()
+            if ncols != 192:               # columns of absent modules are zero (:1032-1039); present ones are all rewritten
+                ws["cat"].zero_()
             col = 0
             if self.use_ambient:
                 self._ambient(ws, B, col)
@@ -903,7 +976,7 @@ class CognitiveAimModel(nn.Module):
              hist.numel(), st)
         return cw["reward"]
 
-    def _forward_core(self, images, exif_data, curiosity_calls=0, zero_features=False):
+    def _forward_core(self, images, exif_data, curiosity_calls=0, zero_features=False, dst=None):
         images, ws, B = self._prepare(images)
         draws = [self._curiosity_draw(B) for _ in range(curiosity_calls)]
         if zero_features:
@@ -917,9 +990,10 @@ class CognitiveAimModel(nn.Module):
             self._features(images, exif_data, ws, B, graph_key="forward")
         for dr in draws:
             self._curiosity_run(ws, B, dr)
-        depth, conf = self._outputs(ws)
-        self._check_fallback_flags(ws)
-        return depth, conf, (ws["attn"].clone() if self.use_focal else None), ws["fused"].clone()
+        if dst is None:
+            dst = self._new_outputs(B, ws["N"], images.device)
+        self._export(ws, B, dst, ws["attn"] if self.use_focal else None)
+        return dst
 
     def _forward_split(self, images, exif_data, n, zero_features=False):
         """The batch as n contiguous sub-batches, each on a stream of the model's own (its own workspace and
@@ -930,7 +1004,9 @@ class CognitiveAimModel(nn.Module):
             self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
         cur = torch.cuda.current_stream(dev)
         bounds = [(B * i // n, B * (i + 1) // n) for i in range(n)]
-        outs = []
+        p = self.patch_size
+        # the whole batch's result tensors, allocated on the caller's stream; every sub-batch writes its rows
+        whole = self._new_outputs(B, (images.shape[2] // p) * (images.shape[3] // p), dev)
         self._pack()                           # on the caller's stream, once for all sub-batches
         self.__dict__["_sig_fresh"] = True
         try:
@@ -938,12 +1014,13 @@ class CognitiveAimModel(nn.Module):
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
                     ex = None if exif_data is None else {k: v[lo:hi] for k, v in exif_data.items()}
-                    outs.append(self._forward_core(images[lo:hi], ex, zero_features=zero_features))
+                    self._forward_core(images[lo:hi], ex, zero_features=zero_features,
+                                       dst=tuple(None if t is None else t[lo:hi] for t in whole))
         finally:
             self.__dict__["_sig_fresh"] = False
         for st in self._side_streams[:n]:
             cur.wait_stream(st)
-        return tuple(None if outs[0][i] is None else torch.cat([o[i] for o in outs]) for i in range(4))
+        return whole
 
     @torch.no_grad()
     def forward(self, images, exif_data=None, return_attention=False):
@@ -1172,12 +1249,12 @@ class CognitiveAimModel(nn.Module):
                 else:
                     self._linear(wt_k, D, "focal_stream.projection.0", ptr(ws["t256"]), 256, B, act=1)
                     self._linear(ptr(ws["t256"]), 256, "focal_stream.projection.3", cat_k, 192, B)
-            self._linear(ptr(sw["cat"]), 192, "fusion.0", ptr(sw["fused"]), 192, K * B, act=1)
             out = sw["out"]
-            call("cogaim_heads", ptr(sw["fused"]), 192, ptr(f["decision_head.0.weight"]), ptr(f["decision_head.0.bias"]),
+            call("cogaim_fusion_heads", ptr(sw["cat"]), 192, 192, ptr(f["fusion.0.weight"]), ptr(f["fusion.0.bias"]), 192,
+                 ptr(f["decision_head.0.weight"]), ptr(f["decision_head.0.bias"]),
                  ptr(f["confidence_head.0.weight"]), ptr(f["confidence_head.0.bias"]),
                  ptr(f["confidence_head.2.weight"]), ptr(f["confidence_head.2.bias"]),
-                 out.data_ptr(), out.data_ptr() + K * B * 4, K * B, st)
+                 ptr(sw["fused"]), out.data_ptr(), out.data_ptr() + K * B * 4, K * B, st)
 
         ncols = self._features(images, exif_data, ws, B, focal_override=col_focal.append, heads=False,
                                graph_key=("sweep", masks.data_ptr(), K) if mkey else None, tail=tail)

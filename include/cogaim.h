@@ -57,10 +57,12 @@ int cogaim_preprocess_rgb8_batch(const void* items, int n, int max_src_h, const 
  * a partial last round along K over the idle CUs (fp32 partials, summed in fixed order: results
  * stay bit-reproducible).  No counterpart in the reference. */
 long long cogaim_gemm_workspace_bytes(void);
-/* tuning knob: 0 = 128x128-tile kernel for every problem, 1 = 256x256 kernel (one tile per workgroup),
- * 2 (default) = persistent 256x256 kernel; 1 and 2 apply to large problems only.  Any other value: -22.
- * Process-wide and not synchronised: set it before launching from several threads. */
+#ifdef COGAIM_TOOLS
+/* Builds with -DCOGAIM_TOOLS only (tools/wt_build.sh, for same-box A/B timing); the shipped library does not export
+ * it, because it is process-wide and not synchronised.  0 = 128x128-tile kernel for every problem, 1 = 256x256 kernel
+ * (one tile per workgroup), 2 (default) = persistent 256x256 kernel; 1 and 2 apply to large problems only. */
 int cogaim_set_gemm_algo(int algo);
+#endif
 
 /* ---- DINOv2 backbone --------------------------------------------------- */
 
@@ -199,9 +201,11 @@ int cogaim_weighted_tokens_multi(const float* tok, long long tok_stride_b, const
 
 /* nn.Linear (+ReLU) in fp32 for the ambient MLP (src/model.py:37-44), focal projection (:82-87),
  * focal fusion (:342-346), EXIF MLPs (:468-480), fusion (:908-912):
- * out[b*ldo+o] = act(x[b*ldx+:K] . W[o] + bias[o]*bias_scale[b]);  act 0 none, 1 ReLU. */
-int cogaim_linear_f32(const float* x, int ldx, const float* W, const float* bias, const float* bias_scale, float* out,
-                      int ldo, int B, int O, int K, int act, void* stream);
+ * out[b*ldo+o] = act(x[b*ldx+:K] . W[o] + bias[o] + bias2[o]*bias2_scale[b]);  act 0 none, 1 ReLU; bias, bias2 and
+ * bias2_scale may be NULL (scale 1).  One wave per output: the form for layers wide enough to fill the chip
+ * (768 inputs); narrower chains go through cogaim_mlp_chain. */
+int cogaim_linear_f32(const float* x, int ldx, const float* W, const float* bias, const float* bias2,
+                      const float* bias2_scale, float* out, int ldo, int B, int O, int K, int act, void* stream);
 
 /* src/model.py:491-514: camera embedding gather and [focal_length, aperture, log(iso+1)].
  * A camera_idx outside [0, num_embeddings) sets *err_flag = 1 (if not NULL) and fills that image's
@@ -213,6 +217,46 @@ int cogaim_exif_prep(const long long* camera_idx, const float* focal_length, con
 /* src/model.py:925-941,1120-1123: depth = Softplus(Linear), conf = Sigmoid(Linear(1,1)(ReLU(Linear))). */
 int cogaim_heads(const float* fused, int K, const float* wd, const float* bd, const float* wc, const float* bc,
                  const float* w2, const float* b2, float* depth, float* conf, int B, void* stream);
+
+/* Several small Linear layers per image in ONE launch: ambient MLP (src/model.py:37-44), a FocalStream's value
+ * projection + projection MLP (:194, :82-87, :308-311), focal fusion (:342-346, :430), EXIF prior (:465-480, :491-519).
+ * One workgroup per image walks n_layers <= 8 layers; activations stay on chip in an array of 4096 floats that the
+ * offsets below index (narrow layers only: a layer of 768 inputs keeps one workgroup busy for ~20 us, so such layers go
+ * through cogaim_linear_f32, which spreads them over the chip).
+ *   layer l:  buf[out_off + o] = act(W[o, :K] . buf[in_off : in_off + K] + b[o] + b2[o] * scale[image]),  o < O
+ * (b, b2 may be NULL; act 0 none, 1 ReLU; a layer's input and output regions must not overlap).  Before layer 0:
+ * buf[in0_off + i] = sum_{p < in0_parts} in0[image * in0_ld + p * in0_part_stride + i] for i < in0_len, and, when in1
+ * is not NULL, buf[in1_off + i] = in1[image * in1_ld + i] for i < in1_len.  Afterwards
+ * out[image * out_ld + i] = buf[out_off + i] for i < out_len.  W matrices are fp32 [O, K] row-major.
+ * The descriptor is read on the host during the call. */
+typedef struct {
+  const float* W; const float* b; const float* b2;
+  int K, O, act, in_off, out_off, reserved;
+} cogaim_mlp_layer;
+typedef struct {
+  cogaim_mlp_layer layer[8];
+  int n_layers, in0_len, in0_off, in0_parts;
+  const float* in0; long long in0_ld, in0_part_stride;
+  const float* in1; long long in1_ld; int in1_len, in1_off;
+  const float* scale;
+  float* out; long long out_ld; int out_len, out_off;
+} cogaim_mlp_chain_desc;
+int cogaim_mlp_chain(const cogaim_mlp_chain_desc* desc, int B, void* stream);
+
+/* src/model.py:908-912 + 925-941 (applied at :1045, :1120-1123) in one launch: fused [B,F] = ReLU(Linear(K,F)(cat)),
+ * depth = Softplus(Linear(F,1)(fused)), conf = Sigmoid(Linear(1,1)(ReLU(Linear(F,1)(fused)))).  K, F <= 1024. */
+int cogaim_fusion_heads(const float* cat, int ldcat, int K, const float* wf, const float* bf, int F, const float* wd,
+                        const float* bd, const float* wc, const float* bc, const float* w2, const float* b2, float* fused,
+                        float* depth, float* conf, int B, void* stream);
+
+/* No counterpart in the reference (torch returns fresh tensors there): one launch that copies a forward's results
+ * out of fixed workspace buffers into the caller's tensors -- depth / conf [B], fused [B,F] (dst NULL: skipped),
+ * attention [B,N] (dst NULL: skipped) -- and n_flags condition words into `flags_host`, a HOST pointer to page-locked
+ * mapped memory for which cogaim_host_pointer_ok returned 0 (NULL: skipped). */
+int cogaim_export_outputs(const float* depth_src, const float* conf_src, const float* fused_src, int F,
+                          const float* attn_src, int N, float* depth, float* conf, float* fused, float* attn,
+                          const int* flags, int* flags_host, int n_flags, int B, void* stream);
+int cogaim_host_pointer_ok(void* host_ptr);
 
 /* Curiosity module (src/model.py:586-773), the parts that are not plain Linear layers.  Its score never
  * reaches depth or confidence; it is evaluated only in the opt-in faithful mode, for the state it leaves behind

@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     text = open(os.path.join(ROOT, "include", "cogaim.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef COGAIM_TOOLS.*?#endif", "", text, flags=re.S)      # knobs of tools builds, not in the shipped ABI
     return re.findall(r"\b(?:int|long long)\s+(cogaim_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S)
 
 
@@ -27,6 +28,7 @@ def test_library_exports_every_declared_symbol():
         n = 0 if params in ("", "void") else len(params.split(","))
         assert n == len(_lib.SIGNATURES[name]), f"{name}: header has {n} parameters, binding {len(_lib.SIGNATURES[name])}"
     assert handle.cogaim_version() >= 1
+    assert not hasattr(handle, "cogaim_set_gemm_algo")       # the process-wide tuning knob stays out of the shipped library
 
 
 def test_model_refuses_cpu():

@@ -1,6 +1,7 @@
 """Kernel-level parity through the C ABI (ctypes), each against a plain fp32
 PyTorch statement of the same operation on the SAME rounded 16-bit operands."""
 import math
+import os
 
 import pytest
 import torch
@@ -175,13 +176,14 @@ def test_small_kernels():
     B = 5
     x, W, b, bs = rnd(B, 768), rnd(256, 768, scale=768 ** -0.5), rnd(256), rnd(B)
     out = torch.zeros(B, 300, device="cuda")
-    call("cogaim_linear_f32", ptr(x), 768, ptr(W), ptr(b), ptr(bs), out.data_ptr() + 16 * 4, 300, B, 256, 768, 1, stream_ptr())
-    ref = torch.relu(x @ W.t() + b[None] * bs[:, None])
+    b2 = rnd(256)
+    call("cogaim_linear_f32", ptr(x), 768, ptr(W), ptr(b), ptr(b2), ptr(bs), out.data_ptr() + 16 * 4, 300, B, 256, 768, 1, stream_ptr())
+    ref = torch.relu(x @ W.t() + b[None] + b2[None] * bs[:, None])
     assert torch.allclose(out[:, 16:272], ref, rtol=1e-5, atol=1e-5)
     assert torch.count_nonzero(out[:, :16]) == 0 and torch.count_nonzero(out[:, 272:]) == 0
     x3, W3 = rnd(B, 3), rnd(64, 3)
     o3 = torch.empty(B, 64, device="cuda")
-    call("cogaim_linear_f32", ptr(x3), 3, ptr(W3), None, None, ptr(o3), 64, B, 64, 3, 0, stream_ptr())
+    call("cogaim_linear_f32", ptr(x3), 3, ptr(W3), None, None, None, ptr(o3), 64, B, 64, 3, 0, stream_ptr())
     assert torch.allclose(o3, x3 @ W3.t(), rtol=1e-5, atol=1e-6)
     # heads
     f, wd, bd, wc, bc, w2, b2 = rnd(B, 192), rnd(1, 192, scale=0.1), rnd(1) + 1, rnd(1, 192, scale=0.1), rnd(1), rnd(1, 1), rnd(1)
@@ -202,6 +204,79 @@ def test_small_kernels():
     call("cogaim_exif_prep", ptr(bad), ptr(fl), ptr(ap), ptr(iso), ptr(emb), 71, 64, ptr(feat), 128, ptr(cont), B, ptr(err), stream_ptr())
     assert int(err) == 1 and torch.isnan(feat[[1, 3], :64]).all() and torch.equal(feat[[0, 2, 4], :64], emb[bad[[0, 2, 4]]])
     assert torch.allclose(cont, torch.stack([fl, ap, torch.log(iso + 1)], 1), rtol=1e-6)
+
+
+def test_mlp_chain_fusion_heads_and_export():
+    """The single-launch forms of the per-image MLPs (src/model.py:37-44, 82-87, 342-346, 465-519, 908-941) against
+    the same layers written with torch: a chain with summed partial inputs, a second input vector concatenated in
+    front of a layer's output, a scaled second bias, K = 3 (scalar path) and more outputs than one pass of the
+    workgroup covers; fusion + heads; the one-launch export into fresh tensors with the flag words to mapped host
+    memory."""
+    from cognitive_aim_depth_estimation_amd._lib import lib, mlp_chain
+    B, D, parts = 5, 768, 7
+    xp = rnd(B, parts, D)
+    W0, b0, c0, sc = rnd(300, D, scale=D ** -0.5), rnd(300), rnd(300), rnd(B)
+    W1, b1 = rnd(64, 300, scale=300 ** -0.5), rnd(64)
+    out = torch.zeros(B, 100, device="cuda")
+    mlp_chain([(ptr(W0), ptr(b0), ptr(c0), D, 300, 1, 0, 1024), (ptr(W1), ptr(b1), None, 300, 64, 0, 1024, 2048)],
+              ptr(xp), parts * D, D, out.data_ptr() + 8 * 4, 100, 64, 2048, B, in0_parts=parts, in0_part_stride=D, scale=ptr(sc))
+    x = xp.double().sum(1)
+    ref = torch.relu(x @ W0.double().t() + b0.double() + c0.double()[None] * sc.double()[:, None]) @ W1.double().t() + b1.double()
+    assert torch.allclose(out[:, 8:72].double(), ref, rtol=1e-5, atol=1e-5), float((out[:, 8:72].double() - ref).abs().max())
+    assert torch.count_nonzero(out[:, :8]) == 0 and torch.count_nonzero(out[:, 72:]) == 0
+    # EXIF-prior shape: encoder on 3 values, its output behind a 64-wide embedding, fusion over the 128
+    cont, emb = rnd(B, 3), rnd(B, 128)
+    We0, be0, We2, be2 = rnd(64, 3), rnd(64), rnd(64, 64, scale=0.125), rnd(64)
+    Wf0, bf0, Wf3, bf3 = rnd(256, 128, scale=128 ** -0.5), rnd(256), rnd(64, 256, scale=1 / 16), rnd(64)
+    o = torch.empty(B, 64, device="cuda")
+    mlp_chain([(ptr(We0), ptr(be0), None, 3, 64, 1, 0, 2048), (ptr(We2), ptr(be2), None, 64, 64, 0, 2048, 1088),
+               (ptr(Wf0), ptr(bf0), None, 128, 256, 1, 1024, 3072), (ptr(Wf3), ptr(bf3), None, 256, 64, 0, 3072, 0)],
+              ptr(cont), 3, 3, ptr(o), 64, 64, 0, B, in1=ptr(emb), in1_ld=128, in1_len=64, in1_off=1024)
+    enc = torch.relu(cont @ We0.t() + be0) @ We2.t() + be2
+    ref = torch.relu(torch.cat([emb[:, :64], enc], 1) @ Wf0.t() + bf0) @ Wf3.t() + bf3
+    assert torch.allclose(o, ref, rtol=1e-5, atol=1e-5)
+    # overlapping input / output regions, regions past the on-chip array, too many layers: refused
+    L = lib()
+    from cognitive_aim_depth_estimation_amd._lib import MlpChainDesc, MlpLayer
+    import ctypes
+    d = MlpChainDesc()
+    d.layer[0] = MlpLayer(ptr(W1), None, None, 300, 64, 0, 0, 200, 0)
+    d.n_layers, d.in0, d.in0_ld, d.in0_len, d.in0_parts, d.out, d.out_ld, d.out_len = 1, ptr(x.float()), 300, 300, 1, ptr(o), 64, 64
+    assert L.cogaim_mlp_chain(ctypes.byref(d), B, stream_ptr()) == -22
+    d.layer[0] = MlpLayer(ptr(W1), None, None, 300, 64, 0, 0, 4090, 0)
+    assert L.cogaim_mlp_chain(ctypes.byref(d), B, stream_ptr()) == -22
+    d.n_layers = 9
+    assert L.cogaim_mlp_chain(ctypes.byref(d), B, stream_ptr()) == -22
+    # fusion + heads
+    cat, Wf, bf = rnd(B, 192), rnd(192, 192, scale=192 ** -0.5), rnd(192)
+    wd, bd, wc, bc, w2, b2 = rnd(1, 192, scale=0.1), rnd(1) + 1, rnd(1, 192, scale=0.1), rnd(1) + 0.5, rnd(1, 1), rnd(1)
+    cat[0] *= 60                                   # softplus threshold (x > 20 -> x)
+    fused, dc = torch.empty(B, 192, device="cuda"), torch.empty(2, B, device="cuda")
+    call("cogaim_fusion_heads", ptr(cat), 192, 192, ptr(Wf), ptr(bf), 192, ptr(wd), ptr(bd), ptr(wc), ptr(bc), ptr(w2), ptr(b2),
+         ptr(fused), dc.data_ptr(), dc.data_ptr() + B * 4, B, stream_ptr())
+    f = torch.relu(cat.double() @ Wf.double().t() + bf.double())            # row 0 is 60 x larger: absolute slack scales with it
+    assert torch.allclose(fused.double(), f, rtol=1e-5, atol=1e-4), float((fused.double() - f).abs().max())
+    f = fused.double()
+    assert torch.allclose(dc[0].double(), torch.nn.functional.softplus(f @ wd.double().t() + bd.double()).squeeze(1), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(dc[1].double(), torch.sigmoid(torch.relu(f @ wc.double().t() + bc.double()) * w2.double()[0, 0] + b2.double()).squeeze(1),
+                          rtol=1e-5, atol=1e-6)
+    # export
+    N = 37
+    attn = rnd(B, N)
+    flags = torch.arange(64, device="cuda", dtype=torch.int32)
+    host = torch.zeros(64, dtype=torch.int32).pin_memory()
+    assert call("cogaim_host_pointer_ok", host.data_ptr()) == 0
+    assert call("cogaim_host_pointer_ok", torch.zeros(64, dtype=torch.int32).data_ptr()) == -22     # pageable memory
+    d_, c_, f_, a_ = (torch.full(sh, float("nan"), device="cuda") for sh in ((B, 1), (B, 1), (B, 192), (B, N)))
+    call("cogaim_export_outputs", dc.data_ptr(), dc.data_ptr() + B * 4, ptr(fused), 192, ptr(attn), N, ptr(d_), ptr(c_), ptr(f_),
+         ptr(a_), ptr(flags), host.data_ptr(), 64, B, stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(d_[:, 0], dc[0]) and torch.equal(c_[:, 0], dc[1]) and torch.equal(f_, fused) and torch.equal(a_, attn)
+    assert host.tolist() == list(range(64))
+    d2 = torch.zeros(B, 1, device="cuda")
+    call("cogaim_export_outputs", dc.data_ptr(), dc.data_ptr() + B * 4, None, 0, None, 0, ptr(d2), ptr(c_), None, None, None, None, 0,
+         B, stream_ptr())
+    assert torch.equal(d2[:, 0], dc[0])
 
 
 @pytest.mark.parametrize("N", [16, 1369])
@@ -230,19 +305,24 @@ def test_large_gemm_kernels_agree(dtype, M, N, K):
     x0 = rnd(M, N)
     ref = x0 + (A.float() @ W.float().t() + bias) * ls
     outs = []
+    from cognitive_aim_depth_estimation_amd._lib import lib
+    knob = hasattr(lib(), "cogaim_set_gemm_algo")      # tools builds only: forces the kernels a shipped library picks by size
+    routes = ((0, (None, 0)), (1, (None, 0)), (1, WS()), (2, (None, 0)), (2, WS())) if knob else ((2, (None, 0)), (2, WS()))
     try:
-        for algo, ws in ((0, (None, 0)), (1, (None, 0)), (1, WS()), (2, (None, 0)), (2, WS())):
-            call("cogaim_set_gemm_algo", algo)
+        for algo, ws in routes:
+            if knob:
+                call("cogaim_set_gemm_algo", algo)
             x = x0.clone()
             call("cogaim_gemm_residual_f32", ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(x), M, N, K, K, K, N, di, *ws, stream_ptr())
             torch.cuda.synchronize()
             assert torch.allclose(x, ref, rtol=1e-4, atol=2e-4), (algo, float((x - ref).abs().max()))
             outs.append(x)
     finally:
-        call("cogaim_set_gemm_algo", 2)      # the knob is process-wide: never leave it changed for later tests
+        if knob:
+            call("cogaim_set_gemm_algo", 2)      # the knob is process-wide: never leave it changed for later tests
     again = x0.clone()
     call("cogaim_gemm_residual_f32", ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(again), M, N, K, K, K, N, di, *WS(), stream_ptr())
-    assert torch.equal(again, outs[4])          # deterministic
+    assert torch.equal(again, outs[-1])         # deterministic
     out16 = torch.empty(M, N, device="cuda", dtype=tdt)
     call("cogaim_gemm_bias_gelu_half", ptr(A), ptr(W), ptr(bias), ptr(out16), M, N, K, K, K, N, di, *WS(), None, stream_ptr())
     refg = torch.nn.functional.gelu(A.float() @ W.float().t() + bias)
@@ -294,8 +374,7 @@ def test_gemm_rejects_bad_arguments():
     x = torch.zeros(M, N, device="cuda")
     assert L.cogaim_gemm_residual_f32(ptr(A), ptr(W), ptr(bias), ptr(bias), ptr(x), M, N, K, K + 8, K, N - 4, 1, *ws,
                                       stream_ptr()) == -22
-    for knob in (100, 205, 1004, 3, -1):
-        assert L.cogaim_set_gemm_algo(knob) == -22
+    assert not hasattr(L, "cogaim_set_gemm_algo") or "COGAIM_LIB" in os.environ      # tools builds only
     torch.cuda.synchronize()
 
 
