@@ -101,6 +101,48 @@ struct MlpChainDev {
   float* out; long long out_ld; int out_len, out_off;
 };
 
+// One Linear layer on vectors held in LDS by a 16-wave workgroup: a wave owns four outputs at a time (their weight rows'
+// loads are issued together), the lanes stride over K.  `copy` (may be NULL) also receives the outputs.
+__device__ __forceinline__ void mlp_layer(const float* in, float* out, const float* __restrict__ W, const float* __restrict__ b,
+                                          const float* __restrict__ b2, float sc, int K, int O, int act, bool in_aligned,
+                                          int wave, int lane, float* __restrict__ copy) {
+  const bool vec = (K & 3) == 0 && in_aligned && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+#pragma unroll 1
+  for (int o0 = wave * 4; o0 < O; o0 += 64) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = W + (size_t)min(o0 + j, O - 1) * K;
+    if (vec) {
+      for (int k = lane * 4; k < K; k += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(in + k);
+        float4 ww[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ww[j] = *reinterpret_cast<const float4*>(w[j] + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += (a.x * ww[j].x + a.y * ww[j].y) + (a.z * ww[j].z + a.w * ww[j].w);
+      }
+    } else {
+      for (int k = lane; k < K; k += 64) {
+        const float a = in[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += a * w[j][k];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = wave_sum(acc[j]);
+    if (lane < 4 && o0 + lane < O) {
+      const int o = o0 + lane;
+      float y = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+      if (b) y += b[o];
+      if (b2) y += b2[o] * sc;
+      if (act == 1) y = y < 0.f ? 0.f : y;          // ReLU that keeps a NaN a NaN, as torch's does
+      out[o] = y;
+      if (copy) copy[o] = y;
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void mlp_chain_kernel(MlpChainDev d) {
   __shared__ __attribute__((aligned(16))) float buf[MLP_LDS];
   const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -121,41 +163,7 @@ __global__ __launch_bounds__(1024) void mlp_chain_kernel(MlpChainDev d) {
 #pragma unroll 1
   for (int l = 0; l < d.n_layers; ++l) {
     const MlpLayerDev L = d.layer[l];
-    const float* in = buf + L.in_off;
-    const bool vec = ((L.K | L.in_off) & 3) == 0 && (reinterpret_cast<uintptr_t>(L.W) & 15) == 0;
-#pragma unroll 1
-    for (int o0 = wave * 4; o0 < L.O; o0 += 64) {
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* w[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = L.W + (size_t)min(o0 + j, L.O - 1) * L.K;
-      if (vec) {
-        for (int k = lane * 4; k < L.K; k += 256) {
-          const float4 a = *reinterpret_cast<const float4*>(in + k);
-          float4 ww[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) ww[j] = *reinterpret_cast<const float4*>(w[j] + k);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] += (a.x * ww[j].x + a.y * ww[j].y) + (a.z * ww[j].z + a.w * ww[j].w);
-        }
-      } else {
-        for (int k = lane; k < L.K; k += 64) {
-          const float a = in[k];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] += a * w[j][k];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = wave_sum(acc[j]);
-      if (lane < 4 && o0 + lane < L.O) {
-        const int o = o0 + lane;
-        float y = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
-        if (L.b) y += L.b[o];
-        if (L.b2) y += L.b2[o] * sc;
-        if (L.act == 1) y = y < 0.f ? 0.f : y;          // ReLU that keeps a NaN a NaN, as torch's does
-        buf[L.out_off + o] = y;
-      }
-    }
+    mlp_layer(buf + L.in_off, buf + L.out_off, L.W, L.b, L.b2, sc, L.K, L.O, L.act, (L.in_off & 3) == 0, wave, lane, nullptr);
     __syncthreads();
   }
   for (int i = tid; i < d.out_len; i += 1024) d.out[(size_t)img * d.out_ld + i] = buf[d.out_off + i];
@@ -164,29 +172,18 @@ __global__ __launch_bounds__(1024) void mlp_chain_kernel(MlpChainDev d) {
 // fused[b] = relu(Wf cat[b] + bf) (src/model.py:908-912, 1045), then the two heads (:925-941, 1120-1123) from it:
 // one workgroup per image, the fused row stays in LDS.
 constexpr int FH_MAX = 1024;
-__global__ __launch_bounds__(256) void fusion_heads_kernel(const float* __restrict__ cat, int ldcat, int K,
-                                                           const float* __restrict__ wf, const float* __restrict__ bf, int F,
-                                                           const float* __restrict__ wd, const float* __restrict__ bd,
-                                                           const float* __restrict__ wc, const float* __restrict__ bc,
-                                                           const float* __restrict__ w2, const float* __restrict__ b2,
-                                                           float* __restrict__ fused, float* __restrict__ depth,
-                                                           float* __restrict__ conf) {
-  __shared__ float xin[FH_MAX], f[FH_MAX];
+__global__ __launch_bounds__(1024) void fusion_heads_kernel(const float* __restrict__ cat, int ldcat, int K,
+                                                            const float* __restrict__ wf, const float* __restrict__ bf, int F,
+                                                            const float* __restrict__ wd, const float* __restrict__ bd,
+                                                            const float* __restrict__ wc, const float* __restrict__ bc,
+                                                            const float* __restrict__ w2, const float* __restrict__ b2,
+                                                            float* __restrict__ fused, float* __restrict__ depth,
+                                                            float* __restrict__ conf) {
+  __shared__ __attribute__((aligned(16))) float xin[FH_MAX], f[FH_MAX];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < K; i += 256) xin[i] = cat[(size_t)b * ldcat + i];
+  for (int i = tid; i < K; i += 1024) xin[i] = cat[(size_t)b * ldcat + i];
   __syncthreads();
-  for (int o = wave; o < F; o += 4) {
-    const float* w = wf + (size_t)o * K;
-    float acc = 0.f;
-    for (int k = lane; k < K; k += 64) acc += xin[k] * w[k];
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      const float y = acc + bf[o];
-      const float r = y < 0.f ? 0.f : y;                // NaN-keeping ReLU
-      f[o] = r;
-      fused[(size_t)b * F + o] = r;
-    }
-  }
+  mlp_layer(xin, f, wf, bf, nullptr, 1.0f, K, F, 1, true, wave, lane, fused + (size_t)b * F);
   __syncthreads();
   if (wave < 2) {
     const float* w = wave == 0 ? wd : wc;
@@ -199,7 +196,7 @@ __global__ __launch_bounds__(256) void fusion_heads_kernel(const float* __restri
         depth[b] = zd > 20.f ? zd : log1pf(expf(zd));
       } else {
         const float hc = acc + bc[0];
-        const float zc = (hc < 0.f ? 0.f : hc) * w2[0] + b2[0];
+        const float zc = (hc < 0.f ? 0.f : hc) * w2[0] + b2[0];      // NaN-keeping ReLU
         conf[b] = 1.0f / (1.0f + expf(-zc));
       }
     }
@@ -408,7 +405,7 @@ int cogaim_fusion_heads(const float* cat, int ldcat, int K, const float* wf, con
                         float* depth, float* conf, int B, void* stream) {
   if (B <= 0 || K <= 0 || K > FH_MAX || F <= 0 || F > FH_MAX || ldcat < K || !cat || !wf || !bf || !fused || !depth || !conf)
     return COGAIM_EINVAL;
-  hipLaunchKernelGGL(fusion_heads_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, cat, ldcat, K, wf, bf, F, wd, bd, wc,
+  hipLaunchKernelGGL(fusion_heads_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, cat, ldcat, K, wf, bf, F, wd, bd, wc,
                      bc, w2, b2, fused, depth, conf);
   return COGAIM_LAUNCH_CHECK();
 }

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Builds the WORKING TREE's kernels with -DCOGAIM_TOOLS (experiment knobs of cogaim_set_gemm_algo) into
-# tools/ub/libcogaim_<name>.so, for same-box A/B timing next to the shipped library:
-#   tools/wt_build.sh wt && gpurun -- 'COGAIM_LIB=tools/ub/libcogaim_wt.so python tools/gemm_bench.py 300 301'
+# tools/ab/libcogaim_<name>.so, for same-box A/B timing next to the shipped library:
+#   tools/wt_build.sh wt && gpurun -- 'COGAIM_LIB=tools/ab/libcogaim_wt.so python tools/gemm_bench.py 300 301'
 set -euo pipefail
 name=${1:?name}
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -14,6 +14,6 @@ for src in "$root"/cognitive_aim_depth_estimation_amd/csrc/*.hip; do
   objs+=("$tmp/$b.o")
 done
 wait
-mkdir -p "$root/tools/ub"
-timeout 300 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/tools/ub/libcogaim_$name.so" "${objs[@]}"
-echo "built $root/tools/ub/libcogaim_$name.so"
+mkdir -p "$root/tools/ab"
+timeout 300 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/tools/ab/libcogaim_$name.so" "${objs[@]}"
+echo "built $root/tools/ab/libcogaim_$name.so"
