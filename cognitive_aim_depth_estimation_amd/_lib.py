@@ -44,11 +44,12 @@ SIGNATURES = {
     "cogaim_focal_scores_colsum": [P, P, P, P, P, P, I, I, I, LL, I, I, P],
     "cogaim_weighted_tokens_rows": [],
     "cogaim_weighted_tokens": [P, LL, P, P, P, P, P, I, I, I, P],
+    "cogaim_weighted_tokens_parts": [P, LL, P, P, P, I, P, P, P, I, I, I, P],
     "cogaim_weighted_tokens_static": [P, LL, P, P, P, P, I, I, I, P],
     "cogaim_guided_attention": [P, P, P, I, I, F, F, P],
     "cogaim_guided_attention_multi": [P, P, P, I, I, I, F, F, P],
     "cogaim_weighted_tokens_multi": [P, LL, P, P, P, I, I, I, I, P],
-    "cogaim_linear_f32": [P, I, P, P, P, P, P, I, I, I, I, I, P],
+    "cogaim_linear_f32": [P, I, P, P, P, P, I, P, I, I, I, I, I, P],
     "cogaim_exif_prep": [P, P, P, P, P, I, I, P, I, P, I, P, P],
     "cogaim_heads": [P, I, P, P, P, P, P, P, P, P, I, P],
     "cogaim_mlp_chain": [P, I, P],

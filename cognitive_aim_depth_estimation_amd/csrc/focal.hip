@@ -298,30 +298,38 @@ __device__ __forceinline__ void block_sum6_d(double (&v)[6], double* redd) {
 
 // The three deterministic summaries of the attention matrix the reference can end up using (model.py:234-249), per
 // image: cand[0] = column mean + centre bias, cand[1] = diagonal of P + bias, cand[2] = row maximum of P + bias, and
-// {sum, sum of squares} of each in fp64.  cand[0] arrives holding the column SUMS.  P = exp2(S - rmax) * rinv, so
-// its row maximum is rinv itself.  Without a score matrix in memory (S == NULL) cand[1] repeats cand[0].
-__global__ __launch_bounds__(256) void focal_attention_candidates_kernel(const float* __restrict__ cbias,
+// {sum, sum of squares} of each in fp64, per image and per 256-column block of this grid: stats [B][gridDim.x][6].
+// The column sums are reduced here from the per-row-block partials (one thread per column over a wide grid: parts
+// ascending in two running sums, the order of reduce_partials_kernel).  P = exp2(S - rmax) * rinv, so its row maximum
+// is rinv itself.  Without a score matrix in memory (S == NULL) cand[1] repeats cand[0].
+__global__ __launch_bounds__(256) void focal_attention_candidates_kernel(const float* __restrict__ part, int nblk,
+                                                                         const float* __restrict__ cbias,
                                                                          const float* __restrict__ S, int ldS,
                                                                          long long strideS, const float* __restrict__ rmax,
                                                                          const float* __restrict__ rinv, float* cand,
                                                                          double* __restrict__ stats, int B, int N) {
   __shared__ double redd[24];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.y, tid = threadIdx.x, c = blockIdx.x * 256 + tid;
   const size_t plane = (size_t)B * N, row = (size_t)b * N;
   const float invN = 1.0f / (float)N;
   double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int c = tid; c < N; c += 256) {
+  if (c < N) {
+    const float* p = part + (size_t)b * nblk * N + c;
+    float s0 = 0.f, s1 = 0.f;
+    int k = 0;
+    for (; k + 1 < nblk; k += 2) { s0 += p[(size_t)k * N]; s1 += p[(size_t)(k + 1) * N]; }
+    if (k < nblk) s0 += p[(size_t)k * N];
     const float bias = cbias[c], inv = rinv[row + c];
-    const float a0 = cand[row + c] * invN + bias;
+    const float a0 = (s0 + s1) * invN + bias;
     const float a1 = S ? __builtin_amdgcn_exp2f(S[b * strideS + (size_t)c * ldS + c] - rmax[row + c]) * inv + bias : a0;
     const float a2 = inv + bias;
     cand[row + c] = a0; cand[plane + row + c] = a1; cand[2 * plane + row + c] = a2;
-    acc[0] += a0; acc[1] += (double)a0 * a0;
-    acc[2] += a1; acc[3] += (double)a1 * a1;
-    acc[4] += a2; acc[5] += (double)a2 * a2;
+    acc[0] = a0; acc[1] = (double)a0 * a0;
+    acc[2] = a1; acc[3] = (double)a1 * a1;
+    acc[4] = a2; acc[5] = (double)a2 * a2;
   }
   block_sum6_d(acc, redd);
-  if (tid < 6) stats[b * 6 + tid] = acc[tid];
+  if (tid < 6) stats[((size_t)b * gridDim.x + blockIdx.x) * 6 + tid] = acc[tid];
 }
 
 // model.py:242-282 per image.  The cascade `if patch_attention.var() < 1e-6` (unbiased variance over the WHOLE batch)
@@ -338,7 +346,8 @@ __global__ __launch_bounds__(256) void focal_attention_vector_kernel(const float
   __shared__ double redd[24];
   const int b = blockIdx.x, tid = threadIdx.x;
   double tot[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int i = tid; i < B; i += 256) {
+  const int nstat = B * ((N + 255) / 256);             // stats [B][ceil(N / 256)][6] of the candidates kernel
+  for (int i = tid; i < nstat; i += 256) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) tot[k] += stats[i * 6 + k];
   }
@@ -388,11 +397,36 @@ __global__ __launch_bounds__(256) void weighted_tokens_partial_kernel(const floa
                                                                       const float* __restrict__ scale,
                                                                       const float* __restrict__ pe,
                                                                       const float* __restrict__ w,
-                                                                      float* __restrict__ part, int nchunk, int N, int D) {
+                                                                      float* __restrict__ part, int nchunk, int N, int D,
+                                                                      const float* __restrict__ cpart, int cnblk,
+                                                                      float* __restrict__ wsum_part) {
+  __shared__ float w_s[WT_ROWS];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int n0 = chunk * WT_ROWS, n1 = min(N, n0 + WT_ROWS);
   const float* tb = tok + b * tok_stride_b;
-  w += (size_t)blockIdx.z * gridDim.y * N;
+  if (cpart) {
+    // the chunk's weights straight from the column-sum partials [B][cnblk][N] (parts ascending in two running sums: the
+    // order of reduce_partials_kernel), and their sum over the chunk for the caller's sum over all rows
+    if (threadIdx.x < 64) {
+      const int n = n0 + threadIdx.x;
+      float u = 0.f;
+      if (threadIdx.x < WT_ROWS && n < N) {
+        const float* p = cpart + (size_t)b * cnblk * N + n;
+        float s0 = 0.f, s1 = 0.f;
+        int k = 0;
+        for (; k + 1 < cnblk; k += 2) { s0 += p[(size_t)k * N]; s1 += p[(size_t)(k + 1) * N]; }
+        if (k < cnblk) s0 += p[(size_t)k * N];
+        u = s0 + s1;
+      }
+      if (threadIdx.x < WT_ROWS) w_s[threadIdx.x] = u;
+      const float t = wave_sum(u);
+      if (threadIdx.x == 0 && wsum_part) wsum_part[(size_t)b * nchunk + chunk] = t;
+    }
+  } else {
+    w += (size_t)blockIdx.z * gridDim.y * N;
+    if (threadIdx.x < WT_ROWS) w_s[threadIdx.x] = w[(size_t)b * N + min(n0 + (int)threadIdx.x, N - 1)];
+  }
+  __syncthreads();
   part += (size_t)blockIdx.z * gridDim.y * nchunk * D;
   for (int c = threadIdx.x * 4; c < D; c += 1024) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -405,7 +439,7 @@ __global__ __launch_bounds__(256) void weighted_tokens_partial_kernel(const floa
       for (int j = 0; j < 8; ++j) {
         const int n = min(m0 + j, n1 - 1);
         x[j] = *reinterpret_cast<const float4*>(tb + (size_t)n * D + c);
-        wn[j] = w[(size_t)b * N + n];
+        wn[j] = w_s[n - n0];
         sc[j] = scale ? scale[(size_t)b * N + n] : 1.0f;
         p[j] = pe ? *reinterpret_cast<const float4*>(pe + (size_t)n * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -504,20 +538,19 @@ int cogaim_focal_weighted_colsum(const float* S, int ldS, long long strideS, con
   return COGAIM_LAUNCH_CHECK();
 }
 
-// cand [3][B][N], stats fp64 [B][6]: the three candidate summaries of model.py:234-249 and their per-image {sum, sum
-// of squares}.  part [B, nblk, N] column-sum partials (nblk <= 0 = ceil(N / cogaim_focal_colsum_rows())); S may be
+// cand [3][B][N], stats fp64 [B][ceil(N / 256)][6]: the three candidate summaries of model.py:234-249 and their {sum, sum
+// of squares} per image and 256-column block.  part [B, nblk, N] column-sum partials (nblk <= 0 = ceil(N / cogaim_focal_colsum_rows())); S may be
 // NULL when no score matrix is kept in memory (the diagonal candidate then repeats the column mean).
 int cogaim_focal_attention_candidates(const float* part, int nblk, const float* center_bias, const float* S, int ldS,
                                       long long strideS, const float* rmax, const float* rinv, float* cand, double* stats,
                                       int B, int N, void* stream) {
   if (B <= 0 || N <= 0 || (S && ldS < N)) return COGAIM_EINVAL;
   if (nblk <= 0) nblk = (N + CS_ROWS - 1) / CS_ROWS;
-  // the reduced column sums are staged in cand[0] (the kernel reads cand[0][b][c] before overwriting it); the reduction
-  // stays a launch of its own: one thread per column over a wide grid takes 8 us, folded into the one-workgroup-
-  // per-image kernel behind it 40 us (43 dependent-latency loads per column on 16 CUs)
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, part, nblk, cand, N);
-  hipLaunchKernelGGL(focal_attention_candidates_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, center_bias, S, ldS,
-                     strideS, rmax, rinv, cand, stats, B, N);
+  // one launch: the reduction of the partials needs a wide grid (one thread per column; folded into a one-workgroup-
+  // per-image kernel it took 40 us instead of 8: 43 dependent-latency loads per column on 16 CUs), so the candidates
+  // and their statistics are formed on that grid too, the statistics as per-block partial sums
+  hipLaunchKernelGGL(focal_attention_candidates_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, part,
+                     nblk, center_bias, S, ldS, strideS, rmax, rinv, cand, stats, B, N);
   return COGAIM_LAUNCH_CHECK();
 }
 
@@ -555,13 +588,13 @@ int cogaim_weighted_tokens_rows() { return WT_ROWS; }
 // workspace: fp32 [K * B * ceil(N / cogaim_weighted_tokens_rows()) * D]; w [K, B, N] -> out [K, B, D]
 static int weighted_tokens_launch(const float* tok, long long tok_stride_b, const float* scale, const float* pe,
                                   const float* w, float* out, float* workspace, int B, int N, int D, int K,
-                                  void* stream) {
+                                  void* stream, const float* cpart = nullptr, int cnblk = 0, float* wsum_part = nullptr) {
   if (B <= 0 || N <= 0 || D <= 0 || K <= 0 || K > 65535 || (long long)K * B > 65535 || (D & 3) || (tok_stride_b & 3) ||
-      !workspace)
+      !workspace || (!w && !cpart) || (cpart && (cnblk <= 0 || K != 1)))
     return COGAIM_EINVAL;
   const int nchunk = (N + WT_ROWS - 1) / WT_ROWS;
   hipLaunchKernelGGL(weighted_tokens_partial_kernel, dim3(nchunk, B, K), dim3(256), 0, (hipStream_t)stream, tok,
-                     tok_stride_b, scale, pe, w, workspace, nchunk, N, D);
+                     tok_stride_b, scale, pe, w, workspace, nchunk, N, D, cpart, cnblk, wsum_part);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 255) / 256, K * B), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, nchunk, out, D);
   return COGAIM_LAUNCH_CHECK();
@@ -570,6 +603,18 @@ static int weighted_tokens_launch(const float* tok, long long tok_stride_b, cons
 int cogaim_weighted_tokens(const float* tok, long long tok_stride_b, const float* scale, const float* pe, const float* w,
                            float* out, float* workspace, int B, int N, int D, void* stream) {
   return weighted_tokens_launch(tok, tok_stride_b, scale, pe, w, out, workspace, B, N, D, 1, stream);
+}
+
+// cogaim_weighted_tokens with the weights given as column-sum partials: w[b][n] = sum_blk cpart[b][blk][n] (cnblk
+// blocks; <= 0 = ceil(N / cogaim_focal_colsum_rows())), reduced inside the token pass instead of by launches of their
+// own; wsum_part [B][ceil(N / cogaim_weighted_tokens_rows())] (may be NULL) receives the weights' sums per chunk of rows.
+int cogaim_weighted_tokens_parts(const float* tok, long long tok_stride_b, const float* scale, const float* pe,
+                                 const float* cpart, int cnblk, float* out, float* workspace, float* wsum_part, int B,
+                                 int N, int D, void* stream) {
+  if (!cpart) return COGAIM_EINVAL;
+  if (cnblk <= 0) cnblk = (N + CS_ROWS - 1) / CS_ROWS;
+  return weighted_tokens_launch(tok, tok_stride_b, scale, pe, nullptr, out, workspace, B, N, D, 1, stream, cpart, cnblk,
+                                wsum_part);
 }
 
 // K weight vectors per image in one pass over the tokens (instruction sweep): w [K, B, N] -> out [K, B, D];

@@ -7,11 +7,12 @@
 
 namespace {
 
-// out[b*ldo + o] = act(x[b*ldx + :K] . W[o*K + :K] + bias[o] + bias2[o] * bias2_scale[b])
+// out[b*ldo + o] = act(x[b*ldx + :K] . W[o*K + :K] + bias[o] + bias2[o] * sum_{p < scale_parts} bias2_scale[b*scale_parts + p])
 __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ x, int ldx,
                                                          const float* __restrict__ W, const float* __restrict__ bias,
                                                          const float* __restrict__ bias2, const float* __restrict__ bias2_scale,
-                                                         float* __restrict__ out, int ldo, int B, int O, int K, int act) {
+                                                         int scale_parts, float* __restrict__ out, int ldo, int B, int O,
+                                                         int K, int act) {
   const int lane = threadIdx.x & 63;
   const long long wid = blockIdx.x * 4LL + (threadIdx.x >> 6);
   if (wid >= (long long)B * O) return;
@@ -31,7 +32,14 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
   acc = wave_sum(acc);
   if (lane == 0) {
     float y = acc + (bias ? bias[o] : 0.f);
-    if (bias2) y += bias2[o] * (bias2_scale ? bias2_scale[b] : 1.0f);
+    if (bias2) {
+      float sc = 1.0f;
+      if (bias2_scale) {
+        sc = 0.f;
+        for (int p = 0; p < scale_parts; ++p) sc += bias2_scale[(size_t)b * scale_parts + p];      // parts ascending: fixed order
+      }
+      y += bias2[o] * sc;
+    }
     if (act == 1) y = y < 0.f ? 0.f : y;      // ReLU that keeps a NaN a NaN, as torch's does (fmaxf would drop it)
     out[(size_t)b * ldo + o] = y;
   }
@@ -107,6 +115,40 @@ __device__ __forceinline__ void mlp_layer(const float* in, float* out, const flo
                                           const float* __restrict__ b2, float sc, int K, int O, int act, bool in_aligned,
                                           int wave, int lane, float* __restrict__ copy) {
   const bool vec = (K & 3) == 0 && in_aligned && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+  if (vec && K <= 256) {
+    // narrow layer: the lane's one chunk of every weight row of up to four passes (16 outputs) is requested before the
+    // first reduction, so that a layer costs ONE memory round trip however many passes it takes
+#pragma unroll 1
+    for (int o0 = wave * 4; o0 < O; o0 += 256) {
+      const int k = lane * 4;
+      const bool on = k < K;
+      const float4 a = on ? *reinterpret_cast<const float4*>(in + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 ww[4][4];
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          ww[ps][j] = *reinterpret_cast<const float4*>(W + (size_t)min(o0 + 64 * ps + j, O - 1) * K + (on ? k : 0));
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        if (o0 + 64 * ps >= O) break;
+        float acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[j] = wave_sum(on ? (a.x * ww[ps][j].x + a.y * ww[ps][j].y) + (a.z * ww[ps][j].z + a.w * ww[ps][j].w) : 0.f);
+        const int o = o0 + 64 * ps + lane;
+        if (lane < 4 && o < O) {
+          float y = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+          if (b) y += b[o];
+          if (b2) y += b2[o] * sc;
+          if (act == 1) y = y < 0.f ? 0.f : y;
+          out[o] = y;
+          if (copy) copy[o] = y;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll 1
   for (int o0 = wave * 4; o0 < O; o0 += 64) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -364,11 +406,12 @@ int cogaim_curiosity_finish(const float* rec, const float* cls, long long ld_cls
 
 // act: 0 identity, 1 ReLU.  bias / bias2 / bias2_scale may be NULL.
 int cogaim_linear_f32(const float* x, int ldx, const float* W, const float* bias, const float* bias2,
-                      const float* bias2_scale, float* out, int ldo, int B, int O, int K, int act, void* stream) {
-  if (B <= 0 || O <= 0 || K <= 0 || ldx < K || (act != 0 && act != 1)) return COGAIM_EINVAL;
+                      const float* bias2_scale, int scale_parts, float* out, int ldo, int B, int O, int K, int act,
+                      void* stream) {
+  if (B <= 0 || O <= 0 || K <= 0 || ldx < K || (act != 0 && act != 1) || (bias2_scale && scale_parts < 1)) return COGAIM_EINVAL;
   const long long waves = (long long)B * O;
   hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, W,
-                     bias, bias2, bias2_scale, out, ldo, B, O, K, act);
+                     bias, bias2, bias2_scale, scale_parts, out, ldo, B, O, K, act);
   return COGAIM_LAUNCH_CHECK();
 }
 

@@ -513,7 +513,7 @@ class CognitiveAimModel(nn.Module):
             "gemm_ws": torch.empty(call("cogaim_gemm_workspace_bytes"), device=dev, dtype=torch.uint8),
             "rmax": torch.empty(B, N, **f32), "rinv": torch.empty(B, N, **f32),
             "part": torch.empty(B * nblk * N, **f32), "attn": torch.empty(B, N, **f32),
-            "scale": torch.empty(2, B, N, **f32), "stats": torch.empty(B, 6, device=dev, dtype=torch.float64),
+            "scale": torch.empty(2, B, N, **f32), "stats": torch.empty(B * ((N + 255) // 256), 6, device=dev, dtype=torch.float64),
             "cand": torch.empty(3, B, N, **f32),
             "flags": torch.zeros(_FLAG_WORDS, device=dev, dtype=torch.int32),
             # host snapshots of the flag words, one per forward, examined when their copy has landed
@@ -521,7 +521,9 @@ class CognitiveAimModel(nn.Module):
                            "pending": False} for _ in range(_FLAG_SNAPSHOTS)],
             "flag_next": 0,
             "flags_mapped": False,
-            "u": torch.empty(B, N, **f32), "usum": torch.empty(B, **f32),
+            "nchunk": (N + call("cogaim_weighted_tokens_rows") - 1) // call("cogaim_weighted_tokens_rows"),
+            "u": torch.empty(B, N, **f32),
+            "usum": torch.empty(B, (N + call("cogaim_weighted_tokens_rows") - 1) // call("cogaim_weighted_tokens_rows"), **f32),
             "wt": torch.empty(B, D, **f32), "w": torch.empty(B, D, **f32),
             "wtpart": torch.empty(B * ((N + call("cogaim_weighted_tokens_rows") - 1)
                                        // call("cogaim_weighted_tokens_rows")) * D, **f32),
@@ -539,12 +541,13 @@ class CognitiveAimModel(nn.Module):
         return ws
 
     # ------------------------------------------------------------------ kernels
-    def _linear(self, x, ldx, wkey, out, ldo, B, act=0, W=None, bias=None, bias2=None, bias2_scale=None):
+    def _linear(self, x, ldx, wkey, out, ldo, B, act=0, W=None, bias=None, bias2=None, bias2_scale=None, scale_parts=1):
         f = self._packed["f32"]
         W = f[wkey + ".weight"] if W is None else W
         bias = f[wkey + ".bias"] if bias is None else bias
         O, K = W.shape
-        call("cogaim_linear_f32", x, ldx, ptr(W), ptr(bias), ptr(bias2), ptr(bias2_scale), out, ldo, B, O, K, act, stream_ptr())
+        call("cogaim_linear_f32", x, ldx, ptr(W), ptr(bias), ptr(bias2), ptr(bias2_scale), scale_parts, out, ldo, B, O, K,
+             act, stream_ptr())
 
     def _backbone(self, images: Optional[torch.Tensor], shape: Tuple[int, int, int], ws: dict):
         """DINOv2 forward (hf:451-477) -> ws['tokens'] fp32 [B*T, D] (final LayerNorm applied).
@@ -617,12 +620,13 @@ class CognitiveAimModel(nn.Module):
                      N, D, D, N * D, B, dt, st)
             else:
                 call("cogaim_focal_weighted_colsum", S, ldS, N * ldS, ptr(ws["rmax"]), ptr(ws["rinv"]), ptr(ws["attn"]), ptr(ws["part"]), B, N, st)
-            call("cogaim_focal_reduce_u", ptr(ws["part"]), ptr(ws["u"]), ptr(ws["usum"]), B, N, ws["nblk"], st)
-            call("cogaim_weighted_tokens", tok, tstride, s_in, ptr(pe), ptr(ws["u"]), ptr(ws["wt"]), ptr(ws["wtpart"]), B, N, D, st)
+            # u = a^T P is reduced from its partials inside the token pass; its sum per chunk of rows goes to ws['usum']
+            call("cogaim_weighted_tokens_parts", tok, tstride, s_in, ptr(pe), ptr(ws["part"]), ws["nblk"], ptr(ws["wt"]),
+                 ptr(ws["wtpart"]), ptr(ws["usum"]), B, N, D, st)
             # value projection folded into projection.0 (see _pack) + ReLU: wide enough for one wave per output;
             # projection.3 of every iteration runs inside the fusion chain (_focal_fused_into)
             self._linear(ptr(ws["wt"]), D, pfx + "projection.0", ws["t256"].data_ptr() + 256 * i * 4, 256 * I, B, act=1,
-                         W=f["m1"], bias2=f["c1"], bias2_scale=ws["usum"])
+                         W=f["m1"], bias2=f["c1"], bias2_scale=ws["usum"], scale_parts=ws["nchunk"])
         return ws["attn"]
 
     def _focal_fused_into(self, ws, B, col):
@@ -879,20 +883,20 @@ class CognitiveAimModel(nn.Module):
             self._backbone(None, shape, ws)
             if ncols != 192:               # columns of absent modules are zero (:1032-1039); present ones are all rewritten
                 ws["cat"].zero_()
-            col = 0
+            col_a, col_f = 0, 64 * int(self.use_ambient)
+            col_e = col_f + 64 * int(self.use_focal)
+            # (The ambient and EXIF MLPs depend on the backbone only, but running them on a forked stream beside the focal
+            # stream -- a branch of the captured graph -- made the step 1.1 ms SLOWER: 13.88 against 12.73 ms on one box.)
             if self.use_ambient:
-                self._ambient(ws, B, col)
-                col += 64
+                self._ambient(ws, B, col_a)
             if self.use_focal:
                 self._focal(B, ws)
                 if focal_override is None:
-                    self._focal_fused_into(ws, B, col)
+                    self._focal_fused_into(ws, B, col_f)
                 else:
-                    focal_override(col)
-                col += 64
+                    focal_override(col_f)
             if exif_in is not None:
-                self._exif(ws, B, col)
-                col += 64
+                self._exif(ws, B, col_e)
             if heads:           # absent modules leave zero columns, as the reference's zero padding does (:1032-1045)
                 self._heads(ws, B)
             if tail is not None:

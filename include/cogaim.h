@@ -172,6 +172,13 @@ int cogaim_focal_reduce_u(const float* part, float* u, float* usum, int B, int N
 int cogaim_weighted_tokens_rows(void);
 int cogaim_weighted_tokens(const float* tok, long long tok_stride_b, const float* scale, const float* pe, const float* w,
                            float* out, float* workspace, int B, int N, int D, void* stream);
+/* The same with w[b][n] = sum_blk cpart[b][blk][n] (the partial column sums u = a^T P of cogaim_focal_weighted_colsum /
+ * cogaim_focal_scores_colsum, cnblk blocks; <= 0 = ceil(N / cogaim_focal_colsum_rows())) reduced inside the token pass;
+ * wsum_part [B][ceil(N / cogaim_weighted_tokens_rows())] (NULL: skipped) receives sum_n w[b][n] per chunk of rows
+ * (the factor of the value-projection bias, src/model.py:194 under :308). */
+int cogaim_weighted_tokens_parts(const float* tok, long long tok_stride_b, const float* scale, const float* pe,
+                                 const float* cpart, int cnblk, float* out, float* workspace, float* wsum_part, int B,
+                                 int N, int D, void* stream);
 
 /* No counterpart in the reference: cogaim_weighted_tokens for callers that cannot allocate device memory or
  * pass a workspace (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
@@ -201,11 +208,12 @@ int cogaim_weighted_tokens_multi(const float* tok, long long tok_stride_b, const
 
 /* nn.Linear (+ReLU) in fp32 for the ambient MLP (src/model.py:37-44), focal projection (:82-87),
  * focal fusion (:342-346), EXIF MLPs (:468-480), fusion (:908-912):
- * out[b*ldo+o] = act(x[b*ldx+:K] . W[o] + bias[o] + bias2[o]*bias2_scale[b]);  act 0 none, 1 ReLU; bias, bias2 and
- * bias2_scale may be NULL (scale 1).  One wave per output: the form for layers wide enough to fill the chip
- * (768 inputs); narrower chains go through cogaim_mlp_chain. */
+ * out[b*ldo+o] = act(x[b*ldx+:K] . W[o] + bias[o] + bias2[o] * s_b),  s_b = sum_{p < scale_parts} bias2_scale[b*scale_parts+p];
+ * act 0 none, 1 ReLU; bias, bias2 and bias2_scale may be NULL (s_b = 1).  One wave per output: the form for layers wide
+ * enough to fill the chip (768 inputs); narrower chains go through cogaim_mlp_chain. */
 int cogaim_linear_f32(const float* x, int ldx, const float* W, const float* bias, const float* bias2,
-                      const float* bias2_scale, float* out, int ldo, int B, int O, int K, int act, void* stream);
+                      const float* bias2_scale, int scale_parts, float* out, int ldo, int B, int O, int K, int act,
+                      void* stream);
 
 /* src/model.py:491-514: camera embedding gather and [focal_length, aperture, log(iso+1)].
  * A camera_idx outside [0, num_embeddings) sets *err_flag = 1 (if not NULL) and fills that image's

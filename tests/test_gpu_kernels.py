@@ -177,13 +177,16 @@ def test_small_kernels():
     x, W, b, bs = rnd(B, 768), rnd(256, 768, scale=768 ** -0.5), rnd(256), rnd(B)
     out = torch.zeros(B, 300, device="cuda")
     b2 = rnd(256)
-    call("cogaim_linear_f32", ptr(x), 768, ptr(W), ptr(b), ptr(b2), ptr(bs), out.data_ptr() + 16 * 4, 300, B, 256, 768, 1, stream_ptr())
+    bs3 = rnd(B, 3)                                    # the scale of the second bias arrives as three partial sums per row
+    call("cogaim_linear_f32", ptr(x), 768, ptr(W), ptr(b), ptr(b2), ptr(bs3), 3, out.data_ptr() + 16 * 4, 300, B, 256, 768, 1,
+         stream_ptr())
+    bs = bs3.sum(1)
     ref = torch.relu(x @ W.t() + b[None] + b2[None] * bs[:, None])
     assert torch.allclose(out[:, 16:272], ref, rtol=1e-5, atol=1e-5)
     assert torch.count_nonzero(out[:, :16]) == 0 and torch.count_nonzero(out[:, 272:]) == 0
     x3, W3 = rnd(B, 3), rnd(64, 3)
     o3 = torch.empty(B, 64, device="cuda")
-    call("cogaim_linear_f32", ptr(x3), 3, ptr(W3), None, None, None, ptr(o3), 64, B, 64, 3, 0, stream_ptr())
+    call("cogaim_linear_f32", ptr(x3), 3, ptr(W3), None, None, None, 1, ptr(o3), 64, B, 64, 3, 0, stream_ptr())
     assert torch.allclose(o3, x3 @ W3.t(), rtol=1e-5, atol=1e-6)
     # heads
     f, wd, bd, wc, bc, w2, b2 = rnd(B, 192), rnd(1, 192, scale=0.1), rnd(1) + 1, rnd(1, 192, scale=0.1), rnd(1), rnd(1, 1), rnd(1)
@@ -204,6 +207,32 @@ def test_small_kernels():
     call("cogaim_exif_prep", ptr(bad), ptr(fl), ptr(ap), ptr(iso), ptr(emb), 71, 64, ptr(feat), 128, ptr(cont), B, ptr(err), stream_ptr())
     assert int(err) == 1 and torch.isnan(feat[[1, 3], :64]).all() and torch.equal(feat[[0, 2, 4], :64], emb[bad[[0, 2, 4]]])
     assert torch.allclose(cont, torch.stack([fl, ap, torch.log(iso + 1)], 1), rtol=1e-6)
+
+
+def test_weighted_tokens_from_partial_column_sums():
+    """cogaim_weighted_tokens_parts reduces the weights from their partial column sums inside the token pass: the token
+    sums must equal (bit for bit) what reduce_u + cogaim_weighted_tokens give, and the per-chunk weight sums add up to
+    the row sum of the weights."""
+    B, N, D, nblk = 3, 1369, 768, 43
+    rows = call("cogaim_weighted_tokens_rows")
+    nchunk = (N + rows - 1) // rows
+    tok = rnd(B, N + 1, D)
+    scale, pe = 1 + torch.rand(B, N, device="cuda"), rnd(N, D)
+    part = torch.rand(B, nblk, N, device="cuda") / (nblk * N)
+    u, usum = torch.empty(B, N, device="cuda"), torch.empty(B, device="cuda")
+    call("cogaim_focal_reduce_u", ptr(part), ptr(u), ptr(usum), B, N, nblk, stream_ptr())
+    want, ws1 = torch.empty(B, D, device="cuda"), torch.empty(B * nchunk * D, device="cuda")
+    call("cogaim_weighted_tokens", tok.data_ptr() + D * 4, (N + 1) * D, ptr(scale), ptr(pe), ptr(u), ptr(want), ptr(ws1), B, N, D,
+         stream_ptr())
+    got, ws2 = torch.empty(B, D, device="cuda"), torch.empty(B * nchunk * D, device="cuda")
+    wsum = torch.full((B, nchunk), float("nan"), device="cuda")
+    call("cogaim_weighted_tokens_parts", tok.data_ptr() + D * 4, (N + 1) * D, ptr(scale), ptr(pe), ptr(part), nblk, ptr(got),
+         ptr(ws2), ptr(wsum), B, N, D, stream_ptr())
+    assert torch.equal(got, want)
+    assert torch.allclose(wsum.sum(1), usum, rtol=1e-5) and torch.allclose(wsum.sum(1), part.sum((1, 2)), rtol=1e-5)
+    from cognitive_aim_depth_estimation_amd._lib import lib
+    assert lib().cogaim_weighted_tokens_parts(tok.data_ptr(), (N + 1) * D, None, None, None, nblk, ptr(got), ptr(ws2), None, B, N, D,
+                                              stream_ptr()) == -22
 
 
 def test_mlp_chain_fusion_heads_and_export():

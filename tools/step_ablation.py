@@ -32,7 +32,7 @@ args = ap.parse_args()
 D = 768
 SMALL = {"cogaim_mlp_chain", "cogaim_linear_f32", "cogaim_fusion_heads"}
 FOCAL = {"cogaim_focal_prep", "cogaim_gemm_batched_f32", "cogaim_focal_softmax_stats_colsum", "cogaim_focal_attention_candidates",
-         "cogaim_focal_attention_vector", "cogaim_focal_weighted_colsum", "cogaim_focal_reduce_u", "cogaim_weighted_tokens"}
+         "cogaim_focal_attention_vector", "cogaim_focal_weighted_colsum", "cogaim_focal_reduce_u", "cogaim_weighted_tokens", "cogaim_weighted_tokens_parts"}
 
 
 def is_focal_proj(name, a):
