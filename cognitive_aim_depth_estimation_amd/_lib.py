@@ -56,6 +56,7 @@ SIGNATURES = {
     "cogaim_fusion_heads": [P, I, I, P, P, I, P, P, P, P, P, P, P, P, P, I, P],
     "cogaim_export_outputs": [P, P, P, I, P, I, P, P, P, P, P, P, I, I, P],
     "cogaim_host_pointer_ok": [P],
+    "cogaim_allgather_f32": [P, P, LL, P, P],
     "cogaim_heatmap_postprocess": [P, P, I, I, I, P],
     "cogaim_curiosity_sample": [P, P, P, P, P, LL, P, P, I, I, I, P],
     "cogaim_curiosity_finish": [P, P, LL, P, P, P, P, P, P, P, P, P, I, I, I, P],

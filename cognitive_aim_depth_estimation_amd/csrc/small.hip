@@ -4,6 +4,7 @@
 // Batch-many-rows x few-hundred-columns: GEMV class, one wave per output.
 #include "common.h"
 #include "../../include/cogaim.h"
+#include <dlfcn.h>
 
 namespace {
 
@@ -501,6 +502,20 @@ int cogaim_heatmap_postprocess(const float* attn, float* out, int B, int N, int 
   while (npad < N) npad <<= 1;
   hipLaunchKernelGGL(heatmap_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, attn, out, N, G * G, npad);
   return COGAIM_LAUNCH_CHECK();
+}
+
+// All-gather of per-image result rows over RCCL (xGMI inside a node): every rank contributes `count` floats, recvbuf
+// receives world * count in rank order.  `comm` is the caller's ncclComm_t.  RCCL is not a link-time dependency of this
+// library: the entry point is looked up among the libraries the process has already loaded (torch ships one), so a
+// process without RCCL gets -38 instead of a load error.
+int cogaim_allgather_f32(const float* sendbuf, float* recvbuf, long long count, void* comm, void* stream) {
+  if (!sendbuf || !recvbuf || count <= 0 || !comm) return COGAIM_EINVAL;
+  using AllGatherFn = int (*)(const void*, void*, size_t, int, void*, hipStream_t);      // ncclAllGather
+  static AllGatherFn fn = nullptr;                       // looked up again on every call until a loaded RCCL is found
+  if (!fn) fn = reinterpret_cast<AllGatherFn>(dlsym(RTLD_DEFAULT, "ncclAllGather"));
+  if (!fn) return -38;
+  constexpr int kNcclFloat32 = 7;                                                         // ncclFloat in rccl.h
+  return fn(sendbuf, recvbuf, (size_t)count, kNcclFloat32, comm, (hipStream_t)stream) == 0 ? COGAIM_OK : -1;
 }
 
 int cogaim_version() { return 4; }

@@ -266,6 +266,14 @@ int cogaim_export_outputs(const float* depth_src, const float* conf_src, const f
                           const int* flags, int* flags_host, int n_flags, int B, void* stream);
 int cogaim_host_pointer_ok(void* host_ptr);
 
+/* No counterpart in the reference (it runs one image at a time on one device): the gather step of image-sharded
+ * inference.  Every rank contributes `count` floats (its [B_local, 2] depth / confidence rows), recvbuf receives
+ * world * count floats in rank order, over the caller's ncclComm_t (RCCL; xGMI inside a node) on `stream`.
+ * RCCL is looked up at call time among the libraries already loaded into the process: -38 when there is none.
+ * The bundled Python paths (bench.py, inference.py) reach the same collective through torch.distributed, which
+ * owns its communicator; this entry point is for hosts that hold their own. */
+int cogaim_allgather_f32(const float* sendbuf, float* recvbuf, long long count, void* comm, void* stream);
+
 /* Curiosity module (src/model.py:586-773), the parts that are not plain Linear layers.  Its score never
  * reaches depth or confidence; it is evaluated only in the opt-in faithful mode, for the state it leaves behind
  * (exploration_history ring buffer, history_pointer) and the random draws it consumes.

@@ -462,3 +462,33 @@ def test_guided_multi_equals_single_calls():
         assert torch.equal(o1, outm[k])
         ref = torch.einsum("bn,bnd->bd", one, tok[:, 1:])
         assert torch.allclose(o1, ref, rtol=1e-4, atol=1e-5)
+
+
+def test_allgather_entry_point_single_rank():
+    """cogaim_allgather_f32 over a one-rank RCCL communicator (the only world size one GPU offers): the rows come back
+    unchanged; without a communicator the call is refused.  The communicator is made with the RCCL that ships with
+    torch, loaded globally so that the library's run-time lookup finds it."""
+    import ctypes
+    from cognitive_aim_depth_estimation_amd._lib import lib
+    L = lib()
+    x = rnd(32, 2)
+    out = torch.zeros(32, 2, device="cuda")
+    assert L.cogaim_allgather_f32(ptr(x), ptr(out), 64, None, stream_ptr()) == -22
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if not os.path.exists(path):
+        pytest.skip("no RCCL beside torch")
+    rccl = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid, comm = UniqueId(), ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    if rccl.ncclGetUniqueId(ctypes.byref(uid)) != 0 or rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) != 0:
+        pytest.skip("RCCL could not make a one-rank communicator on this box")
+    try:
+        assert L.cogaim_allgather_f32(ptr(x), ptr(out), 64, comm, stream_ptr()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, x)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)

@@ -27,7 +27,8 @@ def short(name):
     for key, tag in (("gemm256p_kernel", "gemm256p"), ("gemm256p_fixup", "gemm256p_fixup"), ("gemm_kernel", "gemm128"),
                      ("mhsa_qkv_kernel", "mhsa"), ("layernorm_kernel", "layernorm")):
         if key in name:
-            epi = [e for e in ("EpiBiasGeluHalf", "EpiBiasHalf", "EpiResidualF32", "EpiStoreF32", "EpiPatchEmbed") if e in name]
+            epi = [e for e in ("EpiBiasGeluHalf", "EpiBiasHalf", "EpiResidualF32", "EpiStoreF32", "EpiPatchEmbed", "EpiRowStats",
+                               "EpiColSum") if e in name]
             return tag + ("<" + epi[0] + ">" if epi else "")
     m = re.search(r"_GLOBAL__N_1(\d+)", name)                 # mangled: _ZN12_GLOBAL__N_1<len><identifier>...
     if m:
