@@ -401,24 +401,32 @@ __global__ __launch_bounds__(256) void weighted_tokens_partial_kernel(const floa
                                                                       const float* __restrict__ cpart, int cnblk,
                                                                       float* __restrict__ wsum_part) {
   __shared__ float w_s[WT_ROWS];
+  __shared__ float w_g[8][WT_ROWS];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int n0 = chunk * WT_ROWS, n1 = min(N, n0 + WT_ROWS);
   const float* tb = tok + b * tok_stride_b;
   if (cpart) {
-    // the chunk's weights straight from the column-sum partials [B][cnblk][N] (parts ascending in two running sums: the
-    // order of reduce_partials_kernel), and their sum over the chunk for the caller's sum over all rows
-    if (threadIdx.x < 64) {
-      const int n = n0 + threadIdx.x;
+    // the chunk's weights straight from the column-sum partials [B][cnblk][N]: thread (g, r) adds blocks g, g + 8, ...
+    // of row n0 + r (a handful of independent loads each instead of cnblk in one thread), then the eight group sums
+    // are added in ascending order: a fixed order, so the result does not depend on timing
+    {
+      const int r = threadIdx.x & (WT_ROWS - 1), g = threadIdx.x / WT_ROWS;      // 256 threads = 8 groups x 32 rows
+      const int n = n0 + r;
       float u = 0.f;
-      if (threadIdx.x < WT_ROWS && n < N) {
+      if (n < N) {
         const float* p = cpart + (size_t)b * cnblk * N + n;
-        float s0 = 0.f, s1 = 0.f;
-        int k = 0;
-        for (; k + 1 < cnblk; k += 2) { s0 += p[(size_t)k * N]; s1 += p[(size_t)(k + 1) * N]; }
-        if (k < cnblk) s0 += p[(size_t)k * N];
-        u = s0 + s1;
+        for (int k = g; k < cnblk; k += 8) u += p[(size_t)k * N];
       }
-      if (threadIdx.x < WT_ROWS) w_s[threadIdx.x] = u;
+      w_g[g][r] = u;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float u = 0.f;
+      if (threadIdx.x < WT_ROWS) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) u += w_g[g][threadIdx.x];
+        w_s[threadIdx.x] = u;
+      }
       const float t = wave_sum(u);
       if (threadIdx.x == 0 && wsum_part) wsum_part[(size_t)b * nchunk + chunk] = t;
     }
