@@ -28,6 +28,7 @@ SIGNATURES = {
     "cogaim_gemm_bias_half": [P, P, P, P, I, I, I, I, I, I, I, F, I, P, LL, P, P],
     "cogaim_mhsa_qkv_fwd": [P, P, I, I, I, I, I, P],
     "cogaim_gemm_residual_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P, LL, P],
+    "cogaim_gemm_residual_layernorm": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P],
     "cogaim_gemm_bias_gelu_half": [P, P, P, P, I, I, I, I, I, I, I, P, LL, P, P],
     "cogaim_focal_prep": [P, LL, P, P, P, I, I, I, I, P],
     "cogaim_gemm_batched_f32": [P, P, P, I, I, I, I, I, I, LL, LL, LL, I, I, P],

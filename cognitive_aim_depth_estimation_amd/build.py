@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcogaim.so")
-SOURCES = ["gemm.hip", "attention.hip", "rowwise.hip", "focal.hip", "small.hip", "preprocess.hip"]
+SOURCES = ["gemm.hip", "gemm_rowln.hip", "attention.hip", "rowwise.hip", "focal.hip", "small.hip", "preprocess.hip"]
 # attention.hip: without NaN-honouring, fmaxf on MFMA results needs no canonicalising v_max (x3 fewer max ops)
 EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
 

@@ -311,6 +311,10 @@ class CognitiveAimModel(nn.Module):
         # workspaces (one per batch shape and stream, each with its captured graphs) kept before the least recently
         # used one is dropped; ~1 GB each at 32 images of 518 x 518
         self.workspace_cache = max(1, int(config.get("workspace_cache", 12)))
+        # attention output projection and the LayerNorm after it as one kernel (width 768 only).  Off by default: the
+        # kernel owns whole rows, so every workgroup streams all of W through LDS, and inside the two-stream forward
+        # at 16 x 518 x 518 it measured 15 us per layer slower than the two launches (alone it ties them at 68 us).
+        self.fuse_out_proj_layernorm = bool(config.get("fuse_out_proj_layernorm", False))
         # replay the per-shape launch sequence as one HIP graph after its first (eager) run
         self.use_graph = bool(config.get("use_hip_graph", os.environ.get("COGAIM_GRAPH", "1") != "0"))
 
@@ -575,8 +579,12 @@ class CognitiveAimModel(nn.Module):
             # one projection GEMM for query | key | value (the query columns carry the softmax scale)
             call("cogaim_gemm_bias_half", h, ptr(L["wqkv"]), ptr(L["bqkv"]), qk, M, 3 * D, D, D, D, 3 * D, D, qscale, dt, gw, gwb, rf, st)
             call("cogaim_mhsa_qkv_fwd", qk, ctx, B, T, H, 3 * D, dt, st)
-            call("cogaim_gemm_residual_f32", ctx, ptr(L["wo"]), ptr(L["bo"]), ptr(L["ls1"]), x, M, D, D, D, D, D, dt, gw, gwb, st)
-            call("cogaim_layernorm", x, ptr(L["g2"]), ptr(L["b2"]), h, M, D, eps, dt, st)
+            if self.fuse_out_proj_layernorm and D == 768:
+                call("cogaim_gemm_residual_layernorm", ctx, ptr(L["wo"]), ptr(L["bo"]), ptr(L["ls1"]), x, ptr(L["g2"]),
+                     ptr(L["b2"]), h, M, D, D, D, D, D, D, eps, dt, st)
+            else:
+                call("cogaim_gemm_residual_f32", ctx, ptr(L["wo"]), ptr(L["bo"]), ptr(L["ls1"]), x, M, D, D, D, D, D, dt, gw, gwb, st)
+                call("cogaim_layernorm", x, ptr(L["g2"]), ptr(L["b2"]), h, M, D, eps, dt, st)
             call("cogaim_gemm_bias_gelu_half", h, ptr(L["w1"]), ptr(L["bf1"]), big, M, 4 * D, D, D, D, 4 * D, dt, gw, gwb, rf, st)
             call("cogaim_gemm_residual_f32", big, ptr(L["w2"]), ptr(L["bf2"]), ptr(L["ls2"]), x, M, D, 4 * D, 4 * D, 4 * D, D, dt, gw, gwb, st)
         call("cogaim_layernorm", x, ptr(pk["gf"]), ptr(pk["bf"]), ws["tokens"].data_ptr(), M, D, eps, 2, st)

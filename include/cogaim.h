@@ -103,6 +103,14 @@ int cogaim_gemm_residual_f32(const void* A, const void* W, const float* bias, co
                              int N, int K, int lda, int ldw, int ldc, int dtype, void* workspace,
                              long long workspace_bytes, void* stream);
 
+/* hf:246-252 output dense + hf:277-278 LayerScale + hf:370 residual as above, and the LayerNorm that reads the new
+ * residual stream (hf:372 norm2) in the same kernel, for N = 768 only (other widths: -22, use the two calls):
+ *   x[M,768] += (A . W^T + bias) * layerscale  (in place, fp32);  h16[M,768] = LayerNorm(x) * gamma + beta.
+ * K a multiple of 32; lda, ldw multiples of 8, ldx, ldh multiples of 4 (elements). */
+int cogaim_gemm_residual_layernorm(const void* A, const void* W, const float* bias, const float* layerscale, float* x,
+                                   const float* gamma, const float* beta, void* h, int M, int N, int K, int lda, int ldw,
+                                   int ldx, int ldh, float eps, int dtype, void* stream);
+
 /* hf:293-295 fc1 + exact (erf) GELU: out16[M,N] = gelu(A . W^T + bias). */
 int cogaim_gemm_bias_gelu_half(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int lda,
                                int ldw, int ldc, int dtype, void* workspace, long long workspace_bytes, int* range_flag,

@@ -69,6 +69,44 @@ def test_gemm_residual_and_gelu(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M", [96, 1000, 1370 * 3 + 5])
+def test_gemm_residual_layernorm_is_the_two_calls_in_one(dtype, M):
+    """Output projection + LayerScale + residual + LayerNorm in one kernel (width 768) against the two entry points it
+    replaces: the residual stream bit for bit (same fused multiply-add per element), the normalised rows to 16-bit
+    rounding (the row sums are formed in a different order), and both against fp32 torch."""
+    di, tdt = DT[dtype]
+    N, K = 768, 768
+    A, W, bias, ls = rnd(M, K + 8, dtype=tdt)[:, :K], rnd(N, K, dtype=tdt, scale=K ** -0.5), rnd(N), 1 + 0.1 * rnd(N)
+    g, b = 1 + 0.1 * rnd(N), 0.1 * rnd(N)
+    x0 = rnd(M, N) * 3 + 0.5
+    x0[:, 5] += 80.0                                      # a massive-activation channel, as the residual stream has
+    x_two, x_one = x0.clone(), x0.clone()
+    h_two = torch.empty(M, N, device="cuda", dtype=tdt)
+    h_one = torch.full((M + 1, N), float("nan"), device="cuda", dtype=tdt)       # one guard row past M
+    call("cogaim_gemm_residual_f32", ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(x_two), M, N, K, K + 8, K, N, di, *WS(), stream_ptr())
+    call("cogaim_layernorm", ptr(x_two), ptr(g), ptr(b), ptr(h_two), M, N, 1e-6, di, stream_ptr())
+    call("cogaim_gemm_residual_layernorm", ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(x_one), ptr(g), ptr(b), ptr(h_one),
+         M, N, K, K + 8, K, N, N, 1e-6, di, stream_ptr())
+    torch.cuda.synchronize()
+    ref_x = x0 + (A.float() @ W.float().t() + bias) * ls
+    assert torch.allclose(x_one, ref_x, rtol=1e-4, atol=1e-4), float((x_one - ref_x).abs().max())
+    assert torch.allclose(x_one, x_two, rtol=0, atol=2e-5), float((x_one - x_two).abs().max())   # K summed in other steps
+    ref_h = torch.nn.functional.layer_norm(x_one, (N,), g, b, 1e-6)
+    tol = 2 ** -8 if dtype == "bf16" else 2 ** -10
+    assert torch.allclose(h_one[:M].float(), ref_h, rtol=tol, atol=tol), float((h_one[:M].float() - ref_h).abs().max())
+    assert torch.isnan(h_one[M].float()).all()            # nothing written past row M
+    close = (h_one[:M].float() - h_two.float()).abs() <= 2 * tol * (1 + h_two.float().abs())
+    assert bool(close.all())
+    # shapes the kernel does not take are refused, nothing launched
+    from cognitive_aim_depth_estimation_amd._lib import lib
+    raw = lib().cogaim_gemm_residual_layernorm
+    assert raw(ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(x_one), ptr(g), ptr(b), ptr(h_one), M, 1024, K, K + 8, K, 1024, 1024,
+               1e-6, di, stream_ptr()) == -22
+    assert raw(ptr(A), ptr(W), ptr(bias), ptr(ls), ptr(x_one), ptr(g), ptr(b), ptr(h_one), M, N, K - 16, K + 8, K, N, N,
+               1e-6, di, stream_ptr()) == -22
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("N,B", [(100, 3), (1369, 3), (1369, 9)])
 def test_gemm_batched_scores(dtype, N, B):
     di, tdt = DT[dtype]

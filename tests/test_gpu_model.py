@@ -61,6 +61,29 @@ def test_golden_forward(dtype, size):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_golden_forward_with_fused_out_projection_layernorm(dtype):
+    """``fuse_out_proj_layernorm``: the attention output projection and norm2 as one kernel.  Same golden vectors, same
+    bars; and close to the default two-launch path (the normalised rows differ by 16-bit roundings only)."""
+    z = load_golden("g7_full_model")
+    fused, _ = synth_model_and_sd(int(z["layers"]), int(z["native_grid"]), seed=int(z["seed"]), dtype=dtype,
+                                  fuse_out_proj_layernorm=True)
+    plain, _ = synth_model_and_sd(int(z["layers"]), int(z["native_grid"]), seed=int(z["seed"]), dtype=dtype)
+    assert fused.fuse_out_proj_layernorm and not plain.fuse_out_proj_layernorm
+    for size in (56, 224):
+        key = f"full:{size}"
+        x = torch.from_numpy(z[key + ":x"]).cuda()
+        exif = _golden_exif(z, key, "cuda")
+        d, c, a = fused(x, exif, return_attention=True)
+        e = dict(depth=rel_err(d, torch.from_numpy(z[key + ":depth"])), conf=rel_err(c, torch.from_numpy(z[key + ":conf"])),
+                 attn=rel_err(a, torch.from_numpy(z[key + ":attn"])))
+        report(test="golden_forward_fused_out_ln", dtype=dtype, size=size, **e)
+        assert e["depth"] <= TOL[dtype]["depth_small"] and e["conf"] <= TOL[dtype]["depth_small"], e
+        assert e["attn"] <= TOL[dtype]["attn"], e
+        d0, c0, _ = plain(x, exif, return_attention=True)
+        assert rel_err(d, d0) <= TOL[dtype]["depth_small"] and rel_err(c, c0) <= TOL[dtype]["depth_small"]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_golden_guided(dtype):
     """9-instruction sweep: guided attention heat-maps against the reference's."""
     z = load_golden("g7_full_model")

@@ -14,12 +14,12 @@ def load_golden(name):
 
 
 def synth_model_and_sd(layers, native_grid, iters=3, cams=71, seed=7, dtype="bf16", focus_strength=1.5,
-                       device="cuda"):
+                       device="cuda", **extra_cfg):
     """Product model + the identical synthetic state_dict (CPU fp32) for the oracle."""
     from cognitive_aim_depth_estimation_amd import create_model
     cfg = {"cognitive_modules": MODULES, "compute_dtype": dtype,
            "focal_config": {"num_iterations": iters, "focus_strength": focus_strength},
-           "backbone_config": {"num_hidden_layers": layers, "image_size": 14 * native_grid}}
+           "backbone_config": {"num_hidden_layers": layers, "image_size": 14 * native_grid}, **extra_cfg}
     model = create_model(cfg, {"num_cameras": cams} if cams else None, device=device)
     spec = reference_state_spec(layers=layers, native_grid=native_grid, num_iterations=iters, num_cameras=cams)
     sd = synth_state_dict(spec, seed=seed)
