@@ -11,7 +11,9 @@
 //  * V stays row-major ([token][d], straight out of the fused QKV projection): its
 //    tiles are staged [key][d] in LDS and read with ds_read_b64_tr_b16, which hands
 //    each lane 4 consecutive keys of its d column -- the A operand of O^T += V^T P^T
-//    without a transposed copy in memory.
+//    without a transposed copy in memory;
+//  * K and V tiles reach LDS by 16-byte LDS-DMA (global_load_lds) into the buffer the previous
+//    iteration read, one tile ahead of the math: no staging registers, no ds_write.
 // Q is expected pre-multiplied by dh^-0.5 * log2(e): softmax runs on exp2.
 #include "common.h"
 
@@ -53,41 +55,39 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
     for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const v8*>(qp + 16 * s);
   }
 
-  // staging assignment: thread handles 16-B chunks idx = tid and tid + 256 of each tile
+  // Staging: K and V tiles go global -> LDS by 16-byte LDS-DMA, no register round trip.  A DMA instruction of a wave
+  // fills 1 KiB = 8 tile rows (lane l: row l >> 3, 16-byte position l & 7); the chunk swizzles of the two tile
+  // layouts are applied on the per-lane SOURCE address.  Wave w brings rows 16 w .. 16 w + 15 of both tiles.
   const T* kbase = qk + D + h * 64;
-  const T* vbase = qk + 2 * D + h * 64;
-  // (explicit scalars, not arrays: arrays captured by the staging code end up in scratch)
-  uint4 kreg0, kreg1, vreg0, vreg1;
-  const int sr0 = tid >> 3, sr1 = sr0 + 32, sc = tid & 7;
-#define LOAD_TILE(kv0_)                                                                          \
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
+  const int sr0 = 16 * uwave + (lane >> 3), sr1 = sr0 + 8, sp = lane & 7;
+  const int kc0 = (sp ^ ((sr0 >> 1) & 7)) * 8, kc1 = (sp ^ ((sr1 >> 1) & 7)) * 8;                   // element offsets
+  const int vc0 = D + (sp ^ (((sr0 >> 1) & 1) << 2)) * 8, vc1 = D + (sp ^ (((sr1 >> 1) & 1) << 2)) * 8;
+#define LOAD_TILE(kv0_, buf_)                                                                    \
   {                                                                                              \
     int key0 = (kv0_) + sr0; key0 = key0 < Tn ? key0 : Tn - 1;                                   \
     int key1 = (kv0_) + sr1; key1 = key1 < Tn ? key1 : Tn - 1;                                   \
-    kreg0 = *reinterpret_cast<const uint4*>(kbase + (row0 + key0) * ldqk + sc * 8);              \
-    kreg1 = *reinterpret_cast<const uint4*>(kbase + (row0 + key1) * ldqk + sc * 8);              \
-    vreg0 = *reinterpret_cast<const uint4*>(vbase + (row0 + key0) * ldqk + sc * 8);              \
-    vreg1 = *reinterpret_cast<const uint4*>(vbase + (row0 + key1) * ldqk + sc * 8);              \
+    const T* r0_ = kbase + (row0 + key0) * ldqk;                                                 \
+    const T* r1_ = kbase + (row0 + key1) * ldqk;                                                 \
+    char* ks_ = smem + (buf_) * K_TILE + 2048 * uwave;                                           \
+    char* vs_ = smem + (2 + (buf_)) * K_TILE + 2048 * uwave;                                     \
+    glds16(r0_ + kc0, ks_); glds16(r1_ + kc1, ks_ + 1024);                                       \
+    glds16(r0_ + vc0, vs_); glds16(r1_ + vc1, vs_ + 1024);                                       \
   }
-  // the same for a tile that lies wholly inside the sequence: two running pointers, V at a constant offset
-  // from K, no per-tile index arithmetic (the clamping form above costs ~20 vector instructions a tile)
-  const T* kp0 = kbase + (row0 + sr0) * ldqk + sc * 8;
-  const T* kp1 = kbase + (row0 + sr1) * ldqk + sc * 8;
+  // the same for a tile that lies wholly inside the sequence: two running row pointers, no per-tile index
+  // arithmetic (the clamping form above costs ~20 vector instructions a tile)
+  const T* kp0 = kbase + (row0 + sr0) * ldqk;
+  const T* kp1 = kbase + (row0 + sr1) * ldqk;
   const size_t tile_step = (size_t)KV * ldqk;
-#define LOAD_TILE_INSIDE()                                                                       \
+#define LOAD_TILE_INSIDE(buf_)                                                                   \
   {                                                                                              \
-    kreg0 = *reinterpret_cast<const uint4*>(kp0); kreg1 = *reinterpret_cast<const uint4*>(kp1);  \
-    vreg0 = *reinterpret_cast<const uint4*>(kp0 + D); vreg1 = *reinterpret_cast<const uint4*>(kp1 + D); \
+    char* ks_ = smem + (buf_) * K_TILE + 2048 * uwave;                                           \
+    char* vs_ = smem + (2 + (buf_)) * K_TILE + 2048 * uwave;                                     \
+    glds16(kp0 + kc0, ks_); glds16(kp1 + kc1, ks_ + 1024);                                       \
+    glds16(kp0 + vc0, vs_); glds16(kp1 + vc1, vs_ + 1024);                                       \
     kp0 += tile_step; kp1 += tile_step;                                                          \
   }
-#define STORE_TILE(buf_)                                                                         \
-  {                                                                                              \
-    char* ks_ = smem + (buf_) * K_TILE;                                                          \
-    char* vs_ = smem + (2 + (buf_)) * K_TILE;                                                    \
-    *reinterpret_cast<uint4*>(ks_ + sr0 * 128 + ((sc ^ ((sr0 >> 1) & 7)) << 4)) = kreg0;         \
-    *reinterpret_cast<uint4*>(ks_ + sr1 * 128 + ((sc ^ ((sr1 >> 1) & 7)) << 4)) = kreg1;         \
-    *reinterpret_cast<uint4*>(vs_ + sr0 * 128 + ((sc ^ (((sr0 >> 1) & 1) << 2)) << 4)) = vreg0;  \
-    *reinterpret_cast<uint4*>(vs_ + sr1 * 128 + ((sc ^ (((sr1 >> 1) & 1) << 2)) << 4)) = vreg1;  \
-  }
+#define TILE_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
   // transposed-read addresses inside a V tile: inside its group of 16 lanes, lane 4q + p points at row (key)
   // 4 hh + q, columns (d) 16 dhalf + 4p .. 4p+3 of the d block; rows whose bit 1 is set keep their two 64-B
@@ -106,13 +106,14 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
   float m_run = 0.f, l_run = 0.f;
 
   const int nt = (Tn + KV - 1) / KV;
-  if (nt > 1) LOAD_TILE_INSIDE() else LOAD_TILE(0);
-  STORE_TILE(0);
+  if (nt > 1) LOAD_TILE_INSIDE(0) else LOAD_TILE(0, 0);
+  TILE_LANDED();
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int kv0 = t * KV;
-    if (t + 2 < nt) LOAD_TILE_INSIDE()            // only the last tile can reach past the sequence end
-    else if (t + 1 < nt) LOAD_TILE(kv0 + KV);
+    // the next tile goes straight into the other buffer (last read one iteration ago, before the barrier)
+    if (t + 2 < nt) LOAD_TILE_INSIDE((t + 1) & 1)   // only the last tile can reach past the sequence end
+    else if (t + 1 < nt) LOAD_TILE(kv0 + KV, (t + 1) & 1);
     const char* ks = smem + (t & 1) * K_TILE;
     const char* vs = smem + (2 + (t & 1)) * K_TILE;
 
@@ -190,27 +191,44 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
     l_run += (l4[0] + l4[1]) + (l4[2] + l4[3]);
 
     // O^T += V^T P^T : A = V^T fragment (rows = d), B = P^T fragment (the S^T registers)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int ks2 = 0; ks2 < 2; ++ks2) {
-        v8 pf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (T)s[kb][8 * ks2 + j];
-        // A operand = V^T fragment: rows d = dt*32 + ql, element j = key 16 g + 4 hh + 8 (j >> 2) + (j & 3).
-        // V sits row-major ([key][d]) in LDS; ds_read_b64_tr_b16 hands each lane 4 consecutive keys of its d.
-        const int g = 2 * kb + ks2;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const char* vp = vs + (dt ? vtr1 : vtr0) + g * 2048;
-          const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(vp));
-          const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(vp + 1024));
-          const v8 vf = __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-          o[dt] = Hf::mfma32(vf, pf, o[dt]);
-        }
-      }
+    // A operand = V^T fragment: rows d = dt*32 + ql, element j = key 16 g + 4 hh + 8 (j >> 2) + (j & 3), g = 2 kb + ks2.
+    // V sits row-major ([key][d]) in LDS; ds_read_b64_tr_b16 hands each lane 4 consecutive keys of its d.
+    // The transposed reads are written as asm with hand-counted waits: through the builtin the compiler puts a
+    // vmcnt(0) in front of every one of them while the next tile's LDS-DMA is in flight (it cannot tell that the
+    // DMA fills the other buffer), which would expose the DMA's latency in the middle of every tile.  Two groups of
+    // four reads stay in flight ahead of the MFMAs that use them (LDS operations return in order).
+    const unsigned vs_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)vs;
+    const unsigned va0 = vs_lds + vtr0, va1 = vs_lds + vtr1;
+    s4 vlo[4][2], vhi[4][2];
+#define V_READ(g_)                                                                                                    \
+    asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%6\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\t"                     \
+                 "ds_read_b64_tr_b16 %2, %5 offset:%6\n\tds_read_b64_tr_b16 %3, %5 offset:%7"                          \
+                 : "=&v"(vlo[g_][0]), "=&v"(vhi[g_][0]), "=&v"(vlo[g_][1]), "=&v"(vhi[g_][1])                           \
+                 : "v"(va0), "v"(va1), "n"((g_) * 2048), "n"((g_) * 2048 + 1024) : "memory")
+#define V_WAIT(g_, left_)                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(" #left_ ")"                                                                       \
+                 : "+v"(vlo[g_][0]), "+v"(vhi[g_][0]), "+v"(vlo[g_][1]), "+v"(vhi[g_][1]))
+#define PV(g_)                                                                                                         \
+    {                                                                                                                  \
+      v8 pf;                                                                                                           \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) pf[j] = (T)s[(g_) >> 1][8 * ((g_) & 1) + j];                       \
+      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                               \
+        const v8 vf = __builtin_bit_cast(v8, __builtin_shufflevector(vlo[g_][dt], vhi[g_][dt], 0, 1, 2, 3, 4, 5, 6, 7)); \
+        o[dt] = Hf::mfma32(vf, pf, o[dt]);                                                                             \
+      }                                                                                                                \
+    }
+    V_READ(0); V_READ(1);
+    V_WAIT(0, 4); PV(0);
+    V_READ(2);
+    V_WAIT(1, 4); PV(1);
+    V_READ(3);
+    V_WAIT(2, 4); PV(2);
+    V_WAIT(3, 0); PV(3);
+#undef V_READ
+#undef V_WAIT
+#undef PV
 
-    if (t + 1 < nt) STORE_TILE((t + 1) & 1);
+    TILE_LANDED();
     __syncthreads();
   }
 
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
 
 #undef LOAD_TILE
 #undef LOAD_TILE_INSIDE
-#undef STORE_TILE
+#undef TILE_LANDED
 
 }  // namespace
 
