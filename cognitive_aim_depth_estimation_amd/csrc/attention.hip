@@ -16,6 +16,7 @@
 //    iteration read, one tile ahead of the math: no staging registers, no ds_write.
 // Q is expected pre-multiplied by dh^-0.5 * log2(e): softmax runs on exp2.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -74,18 +75,32 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
     glds16(r0_ + kc0, ks_); glds16(r1_ + kc1, ks_ + 1024);                                       \
     glds16(r0_ + vc0, vs_); glds16(r1_ + vc1, vs_ + 1024);                                       \
   }
-  // the same for a tile that lies wholly inside the sequence: two running row pointers, no per-tile index
-  // arithmetic (the clamping form above costs ~20 vector instructions a tile)
-  const T* kp0 = kbase + (row0 + sr0) * ldqk;
-  const T* kp1 = kbase + (row0 + sr1) * ldqk;
-  const size_t tile_step = (size_t)KV * ldqk;
+  // the same for a tile that lies wholly inside the sequence: a wave-uniform base that advances by one tile and four
+  // fixed 32-bit lane offsets (scalar-base addressing: no vector arithmetic per tile; the clamping form above
+  // costs ~20 vector instructions a tile)
+  unsigned kb_lo, kb_hi;       // forced into scalar registers (the block indices come out of vector divisions)
+  {
+    const unsigned long long p = reinterpret_cast<unsigned long long>(kbase + row0 * ldqk);
+    kb_lo = __builtin_amdgcn_readfirstlane((unsigned)p); kb_hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+  }
+  const unsigned ok0 = (unsigned)(sr0 * ldqk + kc0) * 2u, ok1 = (unsigned)(sr1 * ldqk + kc1) * 2u;
+  const unsigned ov0 = (unsigned)(sr0 * ldqk + vc0) * 2u, ov1 = (unsigned)(sr1 * ldqk + vc1) * 2u;
+  const unsigned long long tile_step = (unsigned long long)KV * ldqk * 2;
+  // (the base passes through an empty asm: otherwise the loop optimiser turns base + offset back into four
+  // per-lane 64-bit pointers that it increments with vector instructions)
 #define LOAD_TILE_INSIDE(buf_)                                                                   \
   {                                                                                              \
     char* ks_ = smem + (buf_) * K_TILE + 2048 * uwave;                                           \
     char* vs_ = smem + (2 + (buf_)) * K_TILE + 2048 * uwave;                                     \
-    glds16(kp0 + kc0, ks_); glds16(kp1 + kc1, ks_ + 1024);                                       \
-    glds16(kp0 + vc0, vs_); glds16(kp1 + vc1, vs_ + 1024);                                       \
-    kp0 += tile_step; kp1 += tile_step;                                                          \
+    asm volatile("" : "+s"(kb_lo), "+s"(kb_hi));                                                 \
+    const unsigned long long kb64_ = ((unsigned long long)kb_hi << 32) | kb_lo;                  \
+    const char* kb_u_ = reinterpret_cast<const char*>(kb64_);                                    \
+    unsigned a_ = ok0, b_ = ok1, c_ = ov0, d_ = ov1;     /* opaque too: a hoisted 64-bit copy loses the scalar-base form */ \
+    asm volatile("" : "+v"(a_), "+v"(b_), "+v"(c_), "+v"(d_));                                   \
+    glds16(kb_u_ + a_, ks_); glds16(kb_u_ + b_, ks_ + 1024);                                     \
+    glds16(kb_u_ + c_, vs_); glds16(kb_u_ + d_, vs_ + 1024);                                     \
+    const unsigned long long nx_ = kb64_ + tile_step;                                            \
+    kb_lo = (unsigned)nx_; kb_hi = (unsigned)(nx_ >> 32);                                        \
   }
 #define TILE_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
@@ -109,13 +124,16 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
   if (nt > 1) LOAD_TILE_INSIDE(0) else LOAD_TILE(0, 0);
   TILE_LANDED();
   __syncthreads();
-  for (int t = 0; t < nt; ++t) {
+  // One key tile.  The buffer index is a compile-time constant (the loop below alternates two copies of this body), so
+  // every LDS address of the tile is a loop-invariant register plus an immediate offset.
+  auto tile = [&](const int t, auto buf_c) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_c)::value;
     const int kv0 = t * KV;
     // the next tile goes straight into the other buffer (last read one iteration ago, before the barrier)
-    if (t + 2 < nt) LOAD_TILE_INSIDE((t + 1) & 1)   // only the last tile can reach past the sequence end
-    else if (t + 1 < nt) LOAD_TILE(kv0 + KV, (t + 1) & 1);
-    const char* ks = smem + (t & 1) * K_TILE;
-    const char* vs = smem + (2 + (t & 1)) * K_TILE;
+    if (t + 2 < nt) LOAD_TILE_INSIDE(BUF ^ 1)       // only the last tile can reach past the sequence end
+    else if (t + 1 < nt) LOAD_TILE(kv0 + KV, BUF ^ 1);
+    const char* ks = smem + BUF * K_TILE;
+    const char* vs = smem + (2 + BUF) * K_TILE;
 
     // S^T = K Q^T - m_run : s[kb][i] = S^T[key kb*32 + (i&3) + 8(i>>2) + 4hh][query ql], already relative
     // to the running maximum (the accumulator starts at -m_run, so no subtraction pass is needed)
@@ -180,15 +198,18 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
         negm[i] = -m_run;
       }
     }
-    float l4[4] = {0.f, 0.f, 0.f, 0.f};
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 l2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};        // two v_pk_add_f32 chains: 16 adds for the 32 values
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < 16; i += 2) {
         s[kb][i] = __builtin_amdgcn_exp2f(s[kb][i]);
-        l4[i & 3] += s[kb][i];
+        s[kb][i + 1] = __builtin_amdgcn_exp2f(s[kb][i + 1]);
+        l2[(i >> 1) & 1] += f32x2{s[kb][i], s[kb][i + 1]};
       }
-    l_run += (l4[0] + l4[1]) + (l4[2] + l4[3]);
+    l2[0] += l2[1];
+    l_run += l2[0][0] + l2[0][1];
 
     // O^T += V^T P^T : A = V^T fragment (rows = d), B = P^T fragment (the S^T registers)
     // A operand = V^T fragment: rows d = dt*32 + ql, element j = key 16 g + 4 hh + 8 (j >> 2) + (j & 3), g = 2 kb + ks2.
@@ -230,6 +251,10 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
 
     TILE_LANDED();
     __syncthreads();
+  };
+  for (int t = 0; t < nt; t += 2) {
+    tile(t, std::integral_constant<int, 0>{});
+    if (t + 1 < nt) tile(t + 1, std::integral_constant<int, 1>{});
   }
 
   // combine the two lane halves' partial sums, normalise, store ctx[b*T+q][h*64 + d]
