@@ -208,8 +208,10 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
         s[kb][i + 1] = __builtin_amdgcn_exp2f(s[kb][i + 1]);
         l2[(i >> 1) & 1] += f32x2{s[kb][i], s[kb][i + 1]};
       }
-    l2[0] += l2[1];
-    l_run += l2[0][0] + l2[0][1];
+    // l2[0] = {sum of elements 0 mod 4, 1 mod 4}, l2[1] = {2 mod 4, 3 mod 4}: combined in the association of four
+    // scalar chains, (c0 + c1) + (c2 + c3).  The 16-bit roundings downstream amplify a last-place change of this
+    // sum into a different draw of the whole forward's rounding error, so the order is part of the pinned numerics.
+    l_run += (l2[0][0] + l2[0][1]) + (l2[1][0] + l2[1][1]);
 
     // O^T += V^T P^T : A = V^T fragment (rows = d), B = P^T fragment (the S^T registers)
     // A operand = V^T fragment: rows d = dt*32 + ql, element j = key 16 g + 4 hh + 8 (j >> 2) + (j & 3), g = 2 kb + ks2.
