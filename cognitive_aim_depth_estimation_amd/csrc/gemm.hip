@@ -53,28 +53,39 @@ __device__ __forceinline__ void store_half8(T* p, const float (&y)[8]) {   // 8 
 // instruction then writes rows 0..7 of the fragment complete, the second rows 8..15.  `row` points at this lane's
 // own row and run 0; rows of a fragment are `ldc` elements apart.  Without the exchange each instruction leaves
 // 16 half-written lines behind.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <class T>
-__device__ __forceinline__ void store_half8x2_lines(T* row, long long ldc, const float (&y0)[8], const float (&y1)[8]) {
-  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pack_half8x2_lines(const float (&y0)[8], const float (&y1)[8], u32x4& first, u32x4& second) {
   alignas(16) T h0[8], h1[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { h0[i] = (T)y0[i]; h1[i] = (T)y1[i]; }
-  const u4 r0 = *reinterpret_cast<const u4*>(h0), r1 = *reinterpret_cast<const u4*>(h1);
+  const u32x4 r0 = *reinterpret_cast<const u32x4*>(h0), r1 = *reinterpret_cast<const u32x4*>(h1);
   const bool low = (threadIdx.x & 8) == 0;              // fr < 8 (fr = lane & 15)
-  u4 give, got;
+  u32x4 give, got;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     give[i] = low ? r1[i] : r0[i];
     got[i] = (unsigned)__builtin_amdgcn_mov_dpp((int)give[i], 0x128 /* row_ror:8 */, 0xf, 0xf, false);
   }
-  u4 first, second;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { first[i] = low ? r0[i] : got[i]; second[i] = low ? got[i] : r1[i]; }
-  // lane fr < 8: rows fr, fr + 8, bytes 0..63;  lane fr >= 8: rows fr - 8, fr, bytes 64..127
-  T* p_first = low ? row : row - 8 * ldc + 32;
-  T* p_second = low ? row + 8 * ldc : row + 32;
-  __builtin_nontemporal_store(first, reinterpret_cast<u4*>(p_first));
-  __builtin_nontemporal_store(second, reinterpret_cast<u4*>(p_second));
+}
+// where the two payloads of pack_half8x2_lines go: lane fr < 8: rows fr, fr + 8, bytes 0..63;  lane fr >= 8: rows
+// fr - 8, fr, bytes 64..127 (`row` = this lane's own row and run 0)
+template <class T>
+__device__ __forceinline__ void line_targets(T* row, long long ldc, T*& p_first, T*& p_second) {
+  const bool low = (threadIdx.x & 8) == 0;
+  p_first = low ? row : row - 8 * ldc + 32;
+  p_second = low ? row + 8 * ldc : row + 32;
+}
+template <class T>
+__device__ __forceinline__ void store_half8x2_lines(T* row, long long ldc, const float (&y0)[8], const float (&y1)[8]) {
+  u32x4 first, second;
+  pack_half8x2_lines<T>(y0, y1, first, second);
+  T *p_first, *p_second;
+  line_targets<T>(row, ldc, p_first, p_second);
+  __builtin_nontemporal_store(first, reinterpret_cast<u32x4*>(p_first));
+  __builtin_nontemporal_store(second, reinterpret_cast<u32x4*>(p_second));
 }
 
 // fp16 range guard.  Outputs stored as fp16 become inf above 65504; the epilogues that store 16-bit values keep a
@@ -159,6 +170,22 @@ template <class T> struct EpiBiasHalf {           // out16 = (acc + bias) [* sca
     }
     track_peak<T, 8>(peak, y[0]); track_peak<T, 8>(peak, y[1]);
     store_half8x2_lines<T>(out + (size_t)m * ldc + n0, ldc, y[0], y[1]);
+  }
+  // the two 16-byte payloads finish8x2n_lines stores, left in registers (kernels that issue the stores later)
+  __device__ __forceinline__ void pack8x2n_lines(int n0, const f32x4 (&v)[4], const float4 (&b)[4], float& peak,
+                                                 u32x4& first, u32x4& second) const {
+    float y[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float s = n0 + 32 * h < scale_cols ? scale : 1.0f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        y[h][4 * q] = (v[2 * h + q][0] + b[2 * h + q].x) * s; y[h][4 * q + 1] = (v[2 * h + q][1] + b[2 * h + q].y) * s;
+        y[h][4 * q + 2] = (v[2 * h + q][2] + b[2 * h + q].z) * s; y[h][4 * q + 3] = (v[2 * h + q][3] + b[2 * h + q].w) * s;
+      }
+    }
+    track_peak<T, 8>(peak, y[0]); track_peak<T, 8>(peak, y[1]);
+    pack_half8x2_lines<T>(y[0], y[1], first, second);
   }
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
     float4 b, l; load_cols(n0, b, l);
@@ -265,6 +292,22 @@ template <class T> struct EpiBiasGeluHalf {
     }
     track_peak<T, 8>(peak, y[0]); track_peak<T, 8>(peak, y[1]);
     store_half8x2_lines<T>(out + (size_t)m * ldc + n0, ldc, y[0], y[1]);
+  }
+  // the two 16-byte payloads finish8x2n_lines stores, left in registers (kernels that issue the stores later)
+  __device__ __forceinline__ void pack8x2n_lines(int, const f32x4 (&v)[4], const float4 (&b)[4], float& peak,
+                                                 u32x4& first, u32x4& second) const {
+    float y[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        y[h][4 * q] = v[2 * h + q][0] + b[2 * h + q].x; y[h][4 * q + 1] = v[2 * h + q][1] + b[2 * h + q].y;
+        y[h][4 * q + 2] = v[2 * h + q][2] + b[2 * h + q].z; y[h][4 * q + 3] = v[2 * h + q][3] + b[2 * h + q].w;
+      }
+      gelu_erf_x8(y[h]);
+    }
+    track_peak<T, 8>(peak, y[0]); track_peak<T, 8>(peak, y[1]);
+    pack_half8x2_lines<T>(y[0], y[1], first, second);
   }
   __device__ __forceinline__ void store4n(int, int m, int n0, f32x4 v) const {
     float4 b, l; load_cols(n0, b, l);
@@ -544,11 +587,13 @@ int g_gemm_quads = 1;       // 0: K-split + fix-up launch for every partial last
 int g_gemm_band = -1;       // tile numbering of the persistent kernel: -1 = chosen per shape (ditto)
 
 #include "gemm_persistent.h"
+#include "gemm_stream.h"
 
+int g_stream_diag = 0; // timing-only variant of the streaming kernel (bit mask, see gemm_stream.h); tools builds only
 int g_gemm_diag = 0;   // timing-only diagnostic variant (wrong results): reachable only in -DCOGAIM_TOOLS builds
 int g_gemm_algo = 2;   // 0: 128x128 kernel everywhere; 1: 256x256 ping-pong kernel, one tile per workgroup;
-                       // 2: persistent 256x256 ping-pong kernel (large problems only for 1 and 2); changed only
-                       // by -DCOGAIM_TOOLS builds
+                       // 2: persistent 256x256 ping-pong kernel (large problems only for 1 and 2); 3: as 2, and the
+                       // 128x256 streaming kernel for the 16-bit-output epilogues; changed only by -DCOGAIM_TOOLS builds
 
 template <class T, class Epi, bool SWAP>
 int launch(const GemmShape& g, const Epi& epi, int batch, hipStream_t st, bool ragged_n = false,
@@ -563,8 +608,11 @@ int launch(const GemmShape& g, const Epi& epi, int batch, hipStream_t st, bool r
     if (tiles2 * batch >= (1 << 30)) return COGAIM_EINVAL;
     return launch_persistent<T, Epi, SWAP>(g, epi, batch, st, nullptr, 0, true, 0);
   }
+  if constexpr (Epi::kWide && SWAP) {
+    if (g_gemm_algo == 3 && stream_eligible<Epi>(g, batch)) return launch_stream<T, Epi>(g, epi, st, g_stream_diag);
+  }
   if (g_gemm_algo >= 1 && tiles2 * batch >= 128 && tiles2 * batch < (1 << 30))
-    return launch_persistent<T, Epi, SWAP>(g, epi, batch, st, workspace, workspace_bytes, g_gemm_algo == 2,
+    return launch_persistent<T, Epi, SWAP>(g, epi, batch, st, workspace, workspace_bytes, g_gemm_algo >= 2,
                                            g_gemm_diag);
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   hipLaunchKernelGGL((gemm_kernel<T, Epi, SWAP>), dim3(tiles, batch), dim3(256), 0, st, g, epi);
@@ -681,12 +729,14 @@ int cogaim_debug_clock(void* dst) {
 // persistent 256x256 kernel (1 and 2 apply to large problems only); the larger codes set the other g_gemm_* values.
 int cogaim_set_gemm_algo(int algo) {
   if (algo >= 1000) { g_gemm_slice_cap = algo - 1000; return COGAIM_OK; }
+  if (algo >= 400 && algo < 432) { g_stream_diag = algo - 400; g_gemm_algo = 3; g_gemm_diag = 0; return COGAIM_OK; }
   if (algo == 300 || algo == 301) { g_gemm_quads = algo - 300; return COGAIM_OK; }
   if (algo >= 200) { g_gemm_band = algo == 299 ? -1 : algo - 200; return COGAIM_OK; }
   if (algo >= 100) { g_gemm_diag = 1; g_gemm_algo = algo - 100; return COGAIM_OK; }
-  if (algo < 0 || algo > 2) return COGAIM_EINVAL;
+  if (algo < 0 || algo > 3) return COGAIM_EINVAL;
   g_gemm_algo = algo;
   g_gemm_diag = 0;
+  g_stream_diag = 0;
   return COGAIM_OK;
 }
 #endif
