@@ -586,8 +586,29 @@ int g_gemm_slice_cap = 0;   // changed only by builds with -DCOGAIM_TOOLS (tools
 int g_gemm_quads = 1;       // 0: K-split + fix-up launch for every partial last round (ditto)
 int g_gemm_band = -1;       // tile numbering of the persistent kernel: -1 = chosen per shape (ditto)
 
+int g_gemm_prefetch = 1;    // whole rounds of large problems on gemm256f_kernel (0: gemm256p_kernel for everything;
+                            // changed only by -DCOGAIM_TOOLS builds)
+int g_prefetch_diag = 0;    // timing-only variant of gemm256f_kernel (bit mask, see gemm_prefetch.h); tools builds only
+template <class T, class Epi> void launch_prefetch(const GemmShape& g, const Epi& epi, const struct PersistSched& sc, hipStream_t st);
+inline bool prefetch_eligible(const GemmShape& g, long long tiles);
 #include "gemm_persistent.h"
+#include "gemm_prefetch.h"
 #include "gemm_stream.h"
+
+template <class T, class Epi>
+void launch_prefetch(const GemmShape& g, const Epi& epi, const PersistSched& sc, hipStream_t st) {
+#ifdef COGAIM_TOOLS
+#define F_DIAG_CASE(d_) \
+  case d_: hipLaunchKernelGGL((gemm256f_kernel<T, Epi, d_>), dim3(256), dim3(512), 0, st, g, epi, sc); break;
+  switch (g_prefetch_diag) {
+    F_DIAG_CASE(1) F_DIAG_CASE(2) F_DIAG_CASE(4) F_DIAG_CASE(8) F_DIAG_CASE(16) F_DIAG_CASE(7)
+    default: hipLaunchKernelGGL((gemm256f_kernel<T, Epi, 0>), dim3(256), dim3(512), 0, st, g, epi, sc);
+  }
+#undef F_DIAG_CASE
+#else
+  hipLaunchKernelGGL((gemm256f_kernel<T, Epi, 0>), dim3(256), dim3(512), 0, st, g, epi, sc);
+#endif
+}
 
 int g_stream_diag = 0; // timing-only variant of the streaming kernel (bit mask, see gemm_stream.h); tools builds only
 int g_gemm_diag = 0;   // timing-only diagnostic variant (wrong results): reachable only in -DCOGAIM_TOOLS builds
@@ -729,11 +750,14 @@ int cogaim_debug_clock(void* dst) {
 // persistent 256x256 kernel (1 and 2 apply to large problems only); the larger codes set the other g_gemm_* values.
 int cogaim_set_gemm_algo(int algo) {
   if (algo >= 1000) { g_gemm_slice_cap = algo - 1000; return COGAIM_OK; }
+  if (algo >= 500 && algo < 532) { g_prefetch_diag = algo - 500; g_gemm_prefetch = 1; g_gemm_algo = 2; g_gemm_diag = 0; return COGAIM_OK; }
   if (algo >= 400 && algo < 432) { g_stream_diag = algo - 400; g_gemm_algo = 3; g_gemm_diag = 0; return COGAIM_OK; }
+  if (algo == 4 || algo == 5) { g_gemm_prefetch = algo - 4; g_prefetch_diag = 0; return COGAIM_OK; }   // 5: on, 4: off
   if (algo == 300 || algo == 301) { g_gemm_quads = algo - 300; return COGAIM_OK; }
   if (algo >= 200) { g_gemm_band = algo == 299 ? -1 : algo - 200; return COGAIM_OK; }
   if (algo >= 100) { g_gemm_diag = 1; g_gemm_algo = algo - 100; return COGAIM_OK; }
   if (algo < 0 || algo > 3) return COGAIM_EINVAL;
+  g_prefetch_diag = 0;
   g_gemm_algo = algo;
   g_gemm_diag = 0;
   g_stream_diag = 0;

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
   const int sb = bid - sc.slice_block0;
   const bool has_slice = !sc.quads && sb >= 0 && sb < sc.n_split * sc.slices;
   const int n_items = full_per_block + (has_slice ? 1 : 0);
-  if (n_items == 0) return;
+  if (n_items == 0 && !sc.quads) return;       // (a launch of the partial last round alone: nblk_full == 0)
 #ifdef COGAIM_STAMPS
   // problem class of the diagnostic clock stamps: 0 = N 3072 (fc1), 1 = N 2304 (QKV), 2 = K 3072 (fc2), 3 = the rest
   const int cclass = g.N == 3072 ? 0 : (g.N == 2304 ? 1 : (g.K == 3072 ? 2 : 3));
@@ -192,6 +192,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
     __builtin_amdgcn_s_setprio(0);                                                                   \
   } while (0)
 
+  if (n_items > 0) {
   // ---- prologue: the first K-tile of the stream into stage 0 --------------------------------------
   dma_set_item(0);
   DMA2(sAe, pAe, 0, 0);
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmShape g, Epi epi, 
 #endif
   }
   if (wr == 0) BARRIER();          // match the extra barrier of the trailing group: both groups are level again
+  }
 #ifdef COGAIM_STAMPS
   if (tid == 0) {
     g_clock_buf[(cclass * 256 + bid) * 4 + 2] = __builtin_amdgcn_s_memtime();
@@ -472,6 +474,19 @@ int launch_persistent(const GemmShape& g, const Epi& epi, int batch, hipStream_t
   sc.nblk_full = persistent ? lanes : sc.n_full;
   sc.slice_block0 = persistent ? 0 : sc.nblk_full;
   const int grid = persistent ? lanes : sc.nblk_full + sc.n_split * sc.slices;
+  if (persistent && g_gemm_prefetch && SWAP && lanes == CUS && prefetch_eligible(g, tiles)) {
+    // whole rounds on the fragment-prefetch kernel, the partial last round (same split as above, same results) behind it
+    launch_prefetch<T, Epi>(g, epi, sc, st);
+    if (rem > 0) {
+      PersistSched tail = sc;
+      tail.nblk_full = 0;           // no whole tiles for anybody: K-slice items or quadrant items only
+      const int tgrid = tail.quads ? CUS : tail.n_split * tail.slices;
+      hipLaunchKernelGGL((gemm256p_kernel<T, Epi, SWAP, 0>), dim3(tgrid), dim3(512), 0, st, g, epi, tail);
+      if (sc.slices >= 2)
+        hipLaunchKernelGGL((gemm256p_fixup_kernel<Epi, SWAP>), dim3(sc.n_split, 32), dim3(512), 0, st, epi, sc);
+    }
+    return COGAIM_LAUNCH_CHECK();
+  }
   if (diag == 1)
     hipLaunchKernelGGL((gemm256p_kernel<T, Epi, SWAP, 1>), dim3(grid), dim3(512), 0, st, g, epi, sc);
   else
