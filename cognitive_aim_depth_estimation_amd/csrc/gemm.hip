@@ -11,6 +11,7 @@
 // Rows past M / N are clamped on load and masked on store, so no padding of the
 // caller's buffers is needed.  K must be a multiple of 64.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -588,10 +589,15 @@ int g_gemm_band = -1;       // tile numbering of the persistent kernel: -1 = cho
 
 int g_gemm_prefetch = 1;    // whole rounds of large problems on gemm256f_kernel (0: gemm256p_kernel for everything;
                             // changed only by -DCOGAIM_TOOLS builds)
+int g_gemm_fast_tail = 2;    // partial last rounds: 2 as items of gemm256f_kernel's first workgroups, 1 on gemm256q_kernel
+                             // behind it, 0 on gemm256p_kernel behind it (changed only by -DCOGAIM_TOOLS builds)
+template <class T, class Epi> void launch_tail(const GemmShape& g, const Epi& epi, const struct PersistSched& tail, hipStream_t st);
+int g_gemm_skip_tail = 0;    // timing-only: leave the partial last round of tiles out (wrong results); tools builds only
 int g_prefetch_diag = 0;    // timing-only variant of gemm256f_kernel (bit mask, see gemm_prefetch.h); tools builds only
 template <class T, class Epi> void launch_prefetch(const GemmShape& g, const Epi& epi, const struct PersistSched& sc, hipStream_t st);
 inline bool prefetch_eligible(const GemmShape& g, long long tiles);
 #include "gemm_persistent.h"
+#include "gemm_tail.h"
 #include "gemm_prefetch.h"
 #include "gemm_stream.h"
 
@@ -610,15 +616,41 @@ void launch_prefetch(const GemmShape& g, const Epi& epi, const PersistSched& sc,
 #endif
 }
 
+template <class T, class Epi>
+void launch_tail(const GemmShape& g, const Epi& epi, const PersistSched& tail, hipStream_t st) {
+  if constexpr (Epi::kReduce == 0)
+    hipLaunchKernelGGL((gemm256q_kernel<T, Epi>), dim3(tail.n_split * tail.slices * 4), dim3(512), 0, st, g, epi, tail);
+}
+
 int g_stream_diag = 0; // timing-only variant of the streaming kernel (bit mask, see gemm_stream.h); tools builds only
 int g_gemm_diag = 0;   // timing-only diagnostic variant (wrong results): reachable only in -DCOGAIM_TOOLS builds
 int g_gemm_algo = 2;   // 0: 128x128 kernel everywhere; 1: 256x256 ping-pong kernel, one tile per workgroup;
                        // 2: persistent 256x256 ping-pong kernel (large problems only for 1 and 2); 3: as 2, and the
                        // 128x256 streaming kernel for the 16-bit-output epilogues; changed only by -DCOGAIM_TOOLS builds
 
+#ifdef COGAIM_TOOLS
+extern "C" int cogaim_set_gemm_algo(int algo);
+// COGAIM_GEMM_KNOBS="5,6": codes of cogaim_set_gemm_algo applied once, for programs that have no call of it (bench.py)
+static void tools_env_once() {
+  static const bool done = [] {
+    if (const char* e = getenv("COGAIM_GEMM_KNOBS"))
+      for (const char* p = e; *p;) {
+        cogaim_set_gemm_algo(atoi(p));
+        while (*p && *p != ',') ++p;
+        if (*p == ',') ++p;
+      }
+    return true;
+  }();
+  (void)done;
+}
+#endif
+
 template <class T, class Epi, bool SWAP>
 int launch(const GemmShape& g, const Epi& epi, int batch, hipStream_t st, bool ragged_n = false,
            void* workspace = nullptr, long long workspace_bytes = 0) {
+#ifdef COGAIM_TOOLS
+  tools_env_once();
+#endif
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (!ragged_n && (g.N & 3) != 0) ||
       (g.lda & 7) != 0 || (g.ldw & 7) != 0 || g.lda < g.K || g.ldw < g.K ||
       ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) != 0 || !g.A || !g.W)
@@ -752,6 +784,8 @@ int cogaim_set_gemm_algo(int algo) {
   if (algo >= 1000) { g_gemm_slice_cap = algo - 1000; return COGAIM_OK; }
   if (algo >= 500 && algo < 532) { g_prefetch_diag = algo - 500; g_gemm_prefetch = 1; g_gemm_algo = 2; g_gemm_diag = 0; return COGAIM_OK; }
   if (algo >= 400 && algo < 432) { g_stream_diag = algo - 400; g_gemm_algo = 3; g_gemm_diag = 0; return COGAIM_OK; }
+  if (algo >= 8 && algo <= 10) { g_gemm_fast_tail = algo - 8; return COGAIM_OK; }       // 10: tails inside gemm256f, 9: gemm256q, 8: gemm256p
+  if (algo == 6 || algo == 7) { g_gemm_skip_tail = algo == 6; return COGAIM_OK; }       // 6: timing-only, no partial last rounds
   if (algo == 4 || algo == 5) { g_gemm_prefetch = algo - 4; g_prefetch_diag = 0; return COGAIM_OK; }   // 5: on, 4: off
   if (algo == 300 || algo == 301) { g_gemm_quads = algo - 300; return COGAIM_OK; }
   if (algo >= 200) { g_gemm_band = algo == 299 ? -1 : algo - 200; return COGAIM_OK; }

@@ -48,6 +48,8 @@ struct PersistSched {
   int slices;
   int slice_block0;   // ... handled by workgroups [slice_block0, slice_block0 + n_split*slices), after their whole tiles
   float* ws;          // [split tile][slice][32 fragments][512 threads] float4 (slices >= 2 only)
+  int tail_items;     // gemm256f_kernel only: workgroups [0, tail_items) run one item (tile, K-slice, quadrant) of the
+                      // partial last round behind their whole tiles (gemm_tail.h), 0: the partial round is launched apart
   int quads;          // 1: tiles [n_full, n_full + n_split) are cut into four QUADRANT items instead (one of the
                       // four 64x32 quadrants of every wave's 128x64, i.e. a quarter of the tile's outputs over
                       // the whole K): no partial sums, no fix-up launch, results bit-identical to a whole tile
@@ -453,7 +455,7 @@ int launch_persistent(const GemmShape& g, const Epi& epi, int batch, hipStream_t
   const int lanes = tiles < CUS ? tiles : CUS;                 // concurrent workgroups
   // 8 x 4 blocks per XCD when the column tiles divide evenly into fours and there is more W than one L2 keeps
   const int band = (g_gemm_band >= 0) ? g_gemm_band : ((tn2 % 4 == 0 && tn2 >= 8) ? 8 : 1);
-  PersistSched sc{tm2, tn2, band, tiles_per_z, (tiles / lanes) * lanes, 0, 0, 1, 0, (float*)workspace, 0};
+  PersistSched sc{tm2, tn2, band, tiles_per_z, (tiles / lanes) * lanes, 0, 0, 1, 0, (float*)workspace, 0, 0};
   const int rem = tiles - sc.n_full;
   if (rem > 0 && persistent && g_gemm_quads && rem * 4 <= lanes && lanes == CUS && nk <= 16 && Epi::kReduce == 0) {
     // a short last round of a short K: quadrant items on 4 x rem workgroups (every workgroup has whole tiles before
@@ -475,13 +477,21 @@ int launch_persistent(const GemmShape& g, const Epi& epi, int batch, hipStream_t
   sc.slice_block0 = persistent ? 0 : sc.nblk_full;
   const int grid = persistent ? lanes : sc.nblk_full + sc.n_split * sc.slices;
   if (persistent && g_gemm_prefetch && SWAP && lanes == CUS && prefetch_eligible(g, tiles)) {
-    // whole rounds on the fragment-prefetch kernel, the partial last round (same split as above, same results) behind it
+    // whole rounds on the fragment-prefetch kernel; the partial last round (same split as above, same results) as
+    // quadrant items of that kernel's first workgroups, or behind it as a launch of its own
+    const bool fast_tail = g_gemm_fast_tail && Epi::kReduce == 0 && rem > 0 && (sc.quads || sc.slices >= 2);
+    if (fast_tail && g_gemm_fast_tail == 2 && rem * sc.slices * 4 <= CUS) sc.tail_items = rem * sc.slices * 4;
     launch_prefetch<T, Epi>(g, epi, sc, st);
-    if (rem > 0) {
+    if (rem > 0 && !g_gemm_skip_tail) {
       PersistSched tail = sc;
       tail.nblk_full = 0;           // no whole tiles for anybody: K-slice items or quadrant items only
-      const int tgrid = tail.quads ? CUS : tail.n_split * tail.slices;
-      hipLaunchKernelGGL((gemm256p_kernel<T, Epi, SWAP, 0>), dim3(tgrid), dim3(512), 0, st, g, epi, tail);
+      if (sc.tail_items) {
+      } else if (fast_tail) {
+        launch_tail<T, Epi>(g, epi, tail, st);     // quadrant items of every tile or K-slice, deep DMA prefetch
+      } else {
+        const int tgrid = tail.quads ? CUS : tail.n_split * tail.slices;
+        hipLaunchKernelGGL((gemm256p_kernel<T, Epi, SWAP, 0>), dim3(tgrid), dim3(512), 0, st, g, epi, tail);
+      }
       if (sc.slices >= 2)
         hipLaunchKernelGGL((gemm256p_fixup_kernel<Epi, SWAP>), dim3(sc.n_split, 32), dim3(512), 0, st, epi, sc);
     }

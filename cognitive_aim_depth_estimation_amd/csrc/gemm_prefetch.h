@@ -313,6 +313,15 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(GemmShape g, Epi epi, 
   }
   F_WAIT(0);                                    // dropped loads past the last tile included
   epi.flush_peak(peak);
+  // ---- the partial last round: one item for each of the first workgroups (gemm_tail.h) ---------------------------
+  if constexpr (Epi::kReduce == 0 && !DIAG) {
+    if ((int)blockIdx.x < sc.tail_items) {
+      int tid_q = tid;
+      asm volatile("" : "+v"(tid_q));             // opaque: see tail_item
+      __builtin_amdgcn_s_barrier();               // every wave is through with the stages
+      tail_item<T, Epi>(g, epi, sc, smem, blockIdx.x, tid_q);
+    }
+  }
 #undef F_KT
 #undef F_PIN4
 #undef F_MATH
