@@ -589,8 +589,9 @@ int g_gemm_band = -1;       // tile numbering of the persistent kernel: -1 = cho
 
 int g_gemm_prefetch = 1;    // whole rounds of large problems on gemm256f_kernel (0: gemm256p_kernel for everything;
                             // changed only by -DCOGAIM_TOOLS builds)
-int g_gemm_fast_tail = 2;    // partial last rounds: 2 as items of gemm256f_kernel's first workgroups, 1 on gemm256q_kernel
-                             // behind it, 0 on gemm256p_kernel behind it (changed only by -DCOGAIM_TOOLS builds)
+int g_gemm_fast_tail = 3;    // partial last rounds: 3 / 2 as items of gemm256f_kernel's first workgroups ahead of / behind
+                             // their whole tiles, 1 on gemm256q_kernel behind it, 0 on gemm256p_kernel behind it
+                             // (changed only by -DCOGAIM_TOOLS builds)
 template <class T, class Epi> void launch_tail(const GemmShape& g, const Epi& epi, const struct PersistSched& tail, hipStream_t st);
 int g_gemm_skip_tail = 0;    // timing-only: leave the partial last round of tiles out (wrong results); tools builds only
 int g_prefetch_diag = 0;    // timing-only variant of gemm256f_kernel (bit mask, see gemm_prefetch.h); tools builds only
@@ -784,7 +785,7 @@ int cogaim_set_gemm_algo(int algo) {
   if (algo >= 1000) { g_gemm_slice_cap = algo - 1000; return COGAIM_OK; }
   if (algo >= 500 && algo < 532) { g_prefetch_diag = algo - 500; g_gemm_prefetch = 1; g_gemm_algo = 2; g_gemm_diag = 0; return COGAIM_OK; }
   if (algo >= 400 && algo < 432) { g_stream_diag = algo - 400; g_gemm_algo = 3; g_gemm_diag = 0; return COGAIM_OK; }
-  if (algo >= 8 && algo <= 10) { g_gemm_fast_tail = algo - 8; return COGAIM_OK; }       // 10: tails inside gemm256f, 9: gemm256q, 8: gemm256p
+  if (algo >= 8 && algo <= 11) { g_gemm_fast_tail = algo - 8; return COGAIM_OK; }       // 11 / 10: tails inside gemm256f ahead of / behind the whole tiles, 9: gemm256q, 8: gemm256p
   if (algo == 6 || algo == 7) { g_gemm_skip_tail = algo == 6; return COGAIM_OK; }       // 6: timing-only, no partial last rounds
   if (algo == 4 || algo == 5) { g_gemm_prefetch = algo - 4; g_prefetch_diag = 0; return COGAIM_OK; }   // 5: on, 4: off
   if (algo == 300 || algo == 301) { g_gemm_quads = algo - 300; return COGAIM_OK; }

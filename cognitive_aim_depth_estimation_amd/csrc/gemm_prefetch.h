@@ -42,6 +42,15 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(GemmShape g, Epi epi, 
   const T* const A0 = reinterpret_cast<const T*>(g.A);
   const T* const W0 = reinterpret_cast<const T*>(g.W);
 
+  // ---- the partial last round AHEAD of the whole tiles (tail_items < 0): its items then start on an idle memory
+  // pipe instead of behind the last tile's epilogue stores, which a wait for any younger DMA piece also waits for
+  if constexpr (Epi::kReduce == 0 && !DIAG) {
+    if ((int)blockIdx.x < -sc.tail_items) {
+      tail_item<T, Epi>(g, epi, sc, smem, blockIdx.x, tid);
+      __builtin_amdgcn_s_barrier();               // the item's LDS reads are done in every wave
+    }
+  }
+
   // ---- DMA side -----------------------------------------------------------------------------------------------
   // A piece is 1 KiB = 8 stage rows.  Each wave brings two pieces of each of the four regions of a stage, named
   // after the fragments read from them: Ae = A rows 0-63 of every wave group (row mod 128 < 64), Al = the other A
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(GemmShape g, Epi epi, 
   }
   F_WAIT(0);                                    // dropped loads past the last tile included
   epi.flush_peak(peak);
-  // ---- the partial last round: one item for each of the first workgroups (gemm_tail.h) ---------------------------
+  // ---- the partial last round behind the whole tiles: one item for each of the first workgroups (gemm_tail.h) ------
   if constexpr (Epi::kReduce == 0 && !DIAG) {
     if ((int)blockIdx.x < sc.tail_items) {
       int tid_q = tid;
