@@ -67,8 +67,8 @@ def gemm_flops(name, args):
 
 
 # C-ABI entry point -> kernel name in the committed rocprofv3 PMC summaries (profiles/*_hbm_traffic.json)
-_PROFILE_KERNEL = {"cogaim_gemm_bias_gelu_half": "gemm256p<EpiBiasGeluHalf>", "cogaim_gemm_bias_half": "gemm256p<EpiBiasHalf>",
-                   "cogaim_gemm_residual_f32": "gemm256p<EpiResidualF32>",
+_PROFILE_KERNEL = {"cogaim_gemm_bias_gelu_half": "gemm256f<EpiBiasGeluHalf>", "cogaim_gemm_bias_half": "gemm256f<EpiBiasHalf>",
+                   "cogaim_gemm_residual_f32": "gemm256f<EpiResidualF32>",
                    "cogaim_mhsa_qkv_fwd": "mhsa", "cogaim_layernorm": "layernorm"}
 
 

@@ -339,6 +339,10 @@ struct EpiResidualF32 {                            // x += (acc + bias) * layers
   }
 };
 
+// epilogues that read-modify-write an fp32 matrix in place through plain pointers (gemm256f_kernel pipelines those)
+template <class E> struct InPlaceRMW { static constexpr bool value = false; };
+template <> struct InPlaceRMW<EpiResidualF32> { static constexpr bool value = true; };
+
 struct EpiStoreF32 {                               // batched plain fp32 store (focal scores)
   static constexpr int kReduce = 0;   // 1 / 2: the tile is reduced in registers instead of stored (EpiRowStats / EpiColSum)
   static constexpr bool kWide = false, kResidual = false;
@@ -600,7 +604,9 @@ inline bool prefetch_eligible(const GemmShape& g, long long tiles);
 #include "gemm_persistent.h"
 #include "gemm_tail.h"
 #include "gemm_prefetch.h"
-#include "gemm_stream.h"
+#ifdef COGAIM_TOOLS
+#include "gemm_stream.h"      // 128x256 streaming kernel: a measured experiment, not part of the shipped library
+#endif
 
 template <class T, class Epi>
 void launch_prefetch(const GemmShape& g, const Epi& epi, const PersistSched& sc, hipStream_t st) {
@@ -662,9 +668,11 @@ int launch(const GemmShape& g, const Epi& epi, int batch, hipStream_t st, bool r
     if (tiles2 * batch >= (1 << 30)) return COGAIM_EINVAL;
     return launch_persistent<T, Epi, SWAP>(g, epi, batch, st, nullptr, 0, true, 0);
   }
+#ifdef COGAIM_TOOLS
   if constexpr (Epi::kWide && SWAP) {
     if (g_gemm_algo == 3 && stream_eligible<Epi>(g, batch)) return launch_stream<T, Epi>(g, epi, st, g_stream_diag);
   }
+#endif
   if (g_gemm_algo >= 1 && tiles2 * batch >= 128 && tiles2 * batch < (1 << 30))
     return launch_persistent<T, Epi, SWAP>(g, epi, batch, st, workspace, workspace_bytes, g_gemm_algo >= 2,
                                            g_gemm_diag);

@@ -186,7 +186,8 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(GemmShape g, Epi epi, 
     }
   }
   int st_cur = 0;                               // stage of the K-tile being computed; the next one is in the other
-  bool stores16 = false;                        // wave-uniform: the last epilogue issued exactly 16 stores and nothing else
+  int first_allow = 3;                          // wave-uniform: what the next tile's first barrier may leave in flight: its own 3
+                                                // pieces plus the stores the last epilogue is known to have issued behind its last wait
 
   // ---- prologue: K-tiles 0 and 1 whole (the first K-tile of a tile expects its successor issued) ----------------
 #pragma unroll
@@ -241,7 +242,9 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(GemmShape g, Epi epi, 
     dma_piece(2);                               // step 7
     F_MATH(ay, wa, 0, 1);
     F_MIX(0, 1, 1);
-    if (FIRST && stores16) F_WAIT(19); else F_WAIT(3);       // all but pieces 0-2 just issued (and 16 epilogue stores)
+    if (FIRST && first_allow == 19) F_WAIT(19);              // all but pieces 0-2 just issued (and the epilogue's last stores)
+    else if (FIRST && first_allow == 11) F_WAIT(11);
+    else F_WAIT(3);
     F_BARRIER();
     F_LOAD_A(ax, st_nxt, 0, 0);                 // step 8
     F_LOAD_W(wa, st_nxt, 0, 0);
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(GemmShape g, Epi epi, 
     // ---- epilogue (that of gemm256p_kernel) ------------------------------------------------------------------
     int z, row0, col0;
     tile_origin(j, z, row0, col0);
-    stores16 = false;
+    first_allow = 3;
     if constexpr ((DIAG & 8) != 0) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(GemmShape g, Epi epi, 
         if (row0 + BM2 <= g.M && col0 + BN2 <= g.N && epi.lines_ok()) {   // wave-uniform
 #pragma unroll
           for (int i = 0; i < 8; ++i) epi.finish8x2n_lines(z, m_base + 16 * i + fr, n_base + 8 * fq, acc[i], cb, peak);
-          stores16 = true;
+          first_allow = 19;
         } else {
 #pragma unroll
           for (int i = 0; i < 8; ++i) epi.finish8x2n(z, m_base + 16 * i + fr, n_base + 8 * fq, acc[i], cb, peak);
@@ -299,6 +302,52 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(GemmShape g, Epi epi, 
           if constexpr (Epi::kColVecs >= 1) F_PIN4(cb[jj]);
           if constexpr (Epi::kColVecs >= 2) F_PIN4(cl[jj]);
         }
+        bool done = false;
+        if constexpr (InPlaceRMW<Epi>::value) {
+          if (row0 + BM2 <= g.M && col0 + BN2 <= g.N) {     // wave-uniform: every lane loads and stores in every part
+            // Two sets of residual values: the loads of part p+1 are issued before the wait for part p, so a part
+            // costs its arithmetic and store issue instead of a memory round trip.  The loads are asm statements
+            // with counted waits: through plain loads the compiler answers every use with vmcnt(0), which also waits
+            // for the previous part's stores.  Younger than the loads of part p at its wait: the 4 stores of part
+            // p-1 and the 4 loads of part p+1.
+            float* const xp = epi.x + (size_t)(m_base + fr) * epi.ldc + n_base + 4 * fq;
+            const size_t pstep = (size_t)16 * epi.ldc;
+            f32x4 xq[2][4];
+#define F_RMW_LOAD(buf_, part_)                                                                      \
+  _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                                   \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xq[buf_][jj]) : "v"(xp + (part_) * pstep + 16 * jj) : "memory")
+#define F_RMW_WAIT(n_, buf_)                                                                         \
+  asm volatile("s_waitcnt vmcnt(" #n_ ")" : "+v"(xq[buf_][0]), "+v"(xq[buf_][1]), "+v"(xq[buf_][2]), "+v"(xq[buf_][3]) :: "memory")
+            F_RMW_LOAD(0, 0);
+#pragma unroll
+            for (int part = 0; part < 8; ++part) {
+              if (part < 7) {
+                if (part & 1) { F_RMW_LOAD(0, part + 1); } else { F_RMW_LOAD(1, part + 1); }
+              }
+              if (part == 0 || part == 7) {
+                if (part & 1) { F_RMW_WAIT(4, 1); } else { F_RMW_WAIT(4, 0); }
+              } else {
+                if (part & 1) { F_RMW_WAIT(8, 1); } else { F_RMW_WAIT(8, 0); }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) {
+                const f32x4 r = xq[part & 1][jj];
+                const f32x4 a = acc[part][jj];
+                float4 o;
+                o.x = r[0] + (a[0] + cb[jj].x) * cl[jj].x; o.y = r[1] + (a[1] + cb[jj].y) * cl[jj].y;
+                o.z = r[2] + (a[2] + cb[jj].z) * cl[jj].z; o.w = r[3] + (a[3] + cb[jj].w) * cl[jj].w;
+                *reinterpret_cast<float4*>(xp + part * pstep + 16 * jj) = o;
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+#undef F_RMW_LOAD
+#undef F_RMW_WAIT
+            first_allow = 11;                                 // the stores of the last two parts may still be in flight
+            done = true;
+          }
+        }
+        if (!done) {
 #pragma unroll
         for (int part = 0; part < 8; ++part) {        // 4 residual loads in flight per lane, then their 4 stores
           float4 xr[4];
@@ -312,6 +361,7 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(GemmShape g, Epi epi, 
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj)
             epi.finish4n(z, m_base + 16 * part + fr, n_base + 16 * jj + 4 * fq, acc[part][jj], cb[jj], cl[jj], xr[jj], peak);
+        }
         }
       }
     }

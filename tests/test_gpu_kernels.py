@@ -366,11 +366,15 @@ def test_guided_attention_kernel(N):
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("M,N,K", [(43840, 768, 768), (40000, 1536, 128), (70000, 768, 3072), (33000, 1280, 64),
-                                   (36000, 1000, 128)])   # ragged last column tile, scale boundary off the 8-column runs
+                                   (36000, 1000, 128),    # ragged last column tile, scale boundary off the 8-column runs
+                                   (21920, 768, 3072), (21920, 2304, 768), (21920, 1000, 768)])
 def test_large_gemm_kernels_agree(dtype, M, N, K):
-    """Large problems take the 256x256 ping-pong kernel (with the split-K tail when a workspace is given);
-    all three routes must agree with fp32 matmul and with each other (bitwise between split / no split is
-    not required: the K-slices change the summation order)."""
+    """Large problems take the 256x256 kernels: whole rounds of tiles on the fragment-prefetch kernel (four K-tiles or
+    more), the partial last round as quadrant items -- of that kernel's first workgroups when there are at most 256
+    of them ((43840, 768, 768): 4 tiles; (21920, 768, 3072): 2 tiles in 8 K-slices each, summed by the fix-up launch),
+    else as a launch of their own ((70000, 768, 3072)) -- and short K on the ping-pong kernel alone.  All routes must
+    agree with fp32 matmul and with each other (bitwise between split / no split is not required: the K-slices
+    change the summation order)."""
     di, tdt = DT[dtype]
     A, W, bias, ls = rnd(M, K, dtype=tdt), rnd(N, K, dtype=tdt, scale=K ** -0.5), rnd(N), 1 + 0.1 * rnd(N)
     x0 = rnd(M, N)

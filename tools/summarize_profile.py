@@ -24,7 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    for key, tag in (("gemm256p_kernel", "gemm256p"), ("gemm256p_fixup", "gemm256p_fixup"), ("gemm_kernel", "gemm128"),
+    for key, tag in (("gemm256f_kernel", "gemm256f"), ("gemm256q_kernel", "gemm256q"), ("gemm128s_kernel", "gemm128s"),
+                     ("gemm256p_kernel", "gemm256p"), ("gemm256p_fixup", "gemm256p_fixup"), ("gemm_kernel", "gemm128"),
                      ("mhsa_qkv_kernel", "mhsa"), ("layernorm_kernel", "layernorm")):
         if key in name:
             epi = [e for e in ("EpiBiasGeluHalf", "EpiBiasHalf", "EpiResidualF32", "EpiStoreF32", "EpiPatchEmbed", "EpiRowStats",
