@@ -172,6 +172,8 @@ def main():
                     help="sub-batches the model runs on streams of its own (0 = the model's default, 2)")
     ap.add_argument("--scores-in-memory", type=int, default=0,
                     help="largest patch grid whose fp32 focal scores are kept in memory (0 = the model's default, 1536)")
+    ap.add_argument("--fuse-out-proj-layernorm", action="store_true",
+                    help="measured alternative, off in the model's default: output projection + norm2 as one whole-row kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--no-second-dtype", action="store_true")
@@ -218,6 +220,8 @@ def main():
             cfg["streams"] = args.streams
         if args.scores_in_memory > 0:
             cfg["focal_scores_in_memory_max_patches"] = args.scores_in_memory
+        if args.fuse_out_proj_layernorm:
+            cfg["fuse_out_proj_layernorm"] = True
         cfg.update(extra)
         return cfg
 

@@ -1,29 +1,32 @@
 // 256x256x64 GEMM main loop with operand fragments read one step ahead (included by gemm.hip, inside its anonymous
-// namespace, after gemm_persistent.h): the whole rounds of tiles of a large problem.  The partial last round stays
-// with gemm256p_kernel (K-slices or quadrant items, unchanged), launched behind this kernel.
+// namespace, after gemm_persistent.h and gemm_tail.h): the whole rounds of tiles of a large problem.  The partial last
+// round runs inside the same launch as items of gemm_tail.h, one per workgroup for the first workgroups, ahead of
+// (or behind) their whole tiles; K-sliced items leave partial sums for gemm256p_fixup_kernel.
 //
-// Same tile, same LDS image, same accumulator layout and same epilogues as gemm256p_kernel, and the same k order per
-// output element, so the results are bit-identical.  What differs is how a K-tile is walked.  gemm256p alternates
-// barrier-delimited LOAD and MATH intervals (eight barriers per K-tile; a wave's MFMAs wait for its own LDS reads,
-// the partner wave group fills the gap).  Here a K-tile is eight steps of 8 MFMAs, one quadrant (64 rows x 32
-// columns) at one k32 half each, ordered so that a step changes ONE operand, and every step issues the LDS reads
-// of the operand the next step changes between its own MFMAs.  Two A buffers and two W buffers of one k32 half
-// (48 registers) are enough for that:
+// Same tile, same 8 waves (2 x 4, 128 x 64 each), same LDS image, same accumulator layout and same epilogues as
+// gemm256p_kernel, and the same k order per output element, so the results are bit-identical.  What differs is how a
+// K-tile is walked.  gemm256p alternates barrier-delimited LOAD and MATH intervals (eight barriers per K-tile; a
+// wave's MFMAs wait for its own LDS reads, the partner wave group fills the gap).  Here a K-tile is eight steps of
+// 8 MFMAs, one quadrant (64 rows x 32 columns) at one k32 half each, ordered so that a step changes ONE operand, and
+// every step issues the LDS reads of the operand the next step changes between its own MFMAs.  Two A buffers and two
+// W buffers of one k32 half (48 registers) are enough for that:
 //   step  quadrant (rows, cols) k32   reads issued meanwhile
 //    1    (0-63,   0-31)  0           W cols 32-63, k32 0
 //    2    (0-63,   32-63) 0           A rows 64-127, k32 0
 //    3    (64-127, 32-63) 0           A rows 64-127, k32 1
-//    4    (64-127, 0-31)  0           W cols 0-31, k32 1
+//    4    (64-127, 0-31)  0           W cols 0-31, k32 1       then: own reads done | BARRIER (regions Al, We free)
 //    5    (64-127, 0-31)  1           W cols 32-63, k32 1
 //    6    (64-127, 32-63) 1           A rows 0-63, k32 1
-//    7    (0-63,   32-63) 1           -            then: own DMA of the next K-tile landed, own reads done | BARRIER
+//    7    (0-63,   32-63) 1           -            then: all but the three youngest DMA pieces landed, own reads done | BARRIER
 //    8    (0-63,   0-31)  1           A rows 0-63 and W cols 0-31, k32 0, of the NEXT K-tile
-// One workgroup barrier per K-tile.  Two 64-KB stages: the stage of K-tile f is refilled (K-tile f+2) from step 8 of
-// K-tile f, after the barrier behind which nobody reads it any more, through step 3 of K-tile f+1, and has until the
-// barrier of K-tile f+1 to land.  The last K-tile of a tile issues all eight pieces of that refill in its step 8,
-// ahead of the epilogue's stores: vector-memory operations retire in order, and the next tile's first barrier
-// must not wait for the stores.  DMA addressing is scalar (a buffer resource per operand and tile, 32-bit lane
-// offsets; rows past the matrix read as zero).
+// Two workgroup barriers per K-tile.  Two 64-KB stages: the stage of K-tile f is refilled (K-tile f+2) one 1-KiB
+// piece per wave and step, in the order its regions fall free -- pieces 0-2 (regions Al, We) in steps 5-7 of K-tile
+// f, pieces 3-7 from step 8 through step 4 of K-tile f+1 -- so the vector-memory path sees an even trickle instead
+// of a burst, and every piece has three steps or more to land.  The last K-tile of a tile issues pieces 3-7 together
+// in its step 8, ahead of the epilogue's stores: vector-memory operations retire in order, and the next tile's
+// barriers must not wait for the stores (first_allow: how many younger operations that wait may leave in flight).
+// DMA addressing is scalar (a buffer resource per operand and tile, 32-bit lane offsets; rows past the matrix read
+// as zero; past the last tile a zero-size resource drops the loads while they still count in vmcnt).
 #pragma once
 #include <type_traits>
 
