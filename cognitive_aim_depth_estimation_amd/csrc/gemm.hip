@@ -598,12 +598,20 @@ int g_gemm_fast_tail = 3;    // partial last rounds: 3 / 2 as items of gemm256f_
                              // (changed only by -DCOGAIM_TOOLS builds)
 template <class T, class Epi> void launch_tail(const GemmShape& g, const Epi& epi, const struct PersistSched& tail, hipStream_t st);
 int g_gemm_skip_tail = 0;    // timing-only: leave the partial last round of tiles out (wrong results); tools builds only
+int g_gemm_wide = 0;       // whole rounds on the four-wave gemm256w_kernel instead (tools builds: knob 13 / 12)
+int g_wide_diag = 0;
+template <class T, class Epi> void launch_wide(const GemmShape& g, const Epi& epi, const struct PersistSched& sc, hipStream_t st, int diag);
 int g_prefetch_diag = 0;    // timing-only variant of gemm256f_kernel (bit mask, see gemm_prefetch.h); tools builds only
 template <class T, class Epi> void launch_prefetch(const GemmShape& g, const Epi& epi, const struct PersistSched& sc, hipStream_t st);
 inline bool prefetch_eligible(const GemmShape& g, long long tiles);
 #include "gemm_persistent.h"
 #include "gemm_tail.h"
 #include "gemm_prefetch.h"
+#if defined(COGAIM_TOOLS) && defined(COGAIM_WIDE)
+#include "gemm_wide.h"     // four-wave 128x128-per-wave kernel: a measured experiment (tools/wt_build.sh with COGAIM_EXTRA_FLAGS=-DCOGAIM_WIDE)
+#else
+template <class T, class Epi> void launch_wide(const GemmShape&, const Epi&, const struct PersistSched&, hipStream_t, int) {}
+#endif
 #ifdef COGAIM_TOOLS
 #include "gemm_stream.h"      // 128x256 streaming kernel: a measured experiment, not part of the shipped library
 #endif
@@ -615,6 +623,7 @@ void launch_prefetch(const GemmShape& g, const Epi& epi, const PersistSched& sc,
   case d_: hipLaunchKernelGGL((gemm256f_kernel<T, Epi, d_>), dim3(256), dim3(512), 0, st, g, epi, sc); break;
   switch (g_prefetch_diag) {
     F_DIAG_CASE(1) F_DIAG_CASE(2) F_DIAG_CASE(4) F_DIAG_CASE(8) F_DIAG_CASE(16) F_DIAG_CASE(7)
+    F_DIAG_CASE(9) F_DIAG_CASE(10) F_DIAG_CASE(12) F_DIAG_CASE(24) F_DIAG_CASE(13) F_DIAG_CASE(15) F_DIAG_CASE(29)
     default: hipLaunchKernelGGL((gemm256f_kernel<T, Epi, 0>), dim3(256), dim3(512), 0, st, g, epi, sc);
   }
 #undef F_DIAG_CASE
@@ -791,6 +800,10 @@ int cogaim_debug_clock(void* dst) {
 // persistent 256x256 kernel (1 and 2 apply to large problems only); the larger codes set the other g_gemm_* values.
 int cogaim_set_gemm_algo(int algo) {
   if (algo >= 1000) { g_gemm_slice_cap = algo - 1000; return COGAIM_OK; }
+#ifdef COGAIM_WIDE
+  if (algo >= 600 && algo < 632) { g_wide_diag = algo - 600; g_gemm_wide = 1; g_gemm_prefetch = 1; g_gemm_algo = 2; g_gemm_diag = 0; return COGAIM_OK; }
+  if (algo == 12 || algo == 13) { g_gemm_wide = algo - 12; g_wide_diag = 0; return COGAIM_OK; }
+#endif
   if (algo >= 500 && algo < 532) { g_prefetch_diag = algo - 500; g_gemm_prefetch = 1; g_gemm_algo = 2; g_gemm_diag = 0; return COGAIM_OK; }
   if (algo >= 400 && algo < 432) { g_stream_diag = algo - 400; g_gemm_algo = 3; g_gemm_diag = 0; return COGAIM_OK; }
   if (algo >= 8 && algo <= 11) { g_gemm_fast_tail = algo - 8; return COGAIM_OK; }       // 11 / 10: tails inside gemm256f ahead of / behind the whole tiles, 9: gemm256q, 8: gemm256p

@@ -480,9 +480,10 @@ int launch_persistent(const GemmShape& g, const Epi& epi, int batch, hipStream_t
     // whole rounds on the fragment-prefetch kernel; the partial last round (same split as above, same results) as
     // quadrant items of that kernel's first workgroups, or behind it as a launch of its own
     const bool fast_tail = g_gemm_fast_tail && Epi::kReduce == 0 && rem > 0 && (sc.quads || sc.slices >= 2);
-    if (fast_tail && g_gemm_fast_tail >= 2 && !g_gemm_skip_tail && rem * sc.slices * 4 <= CUS)
+    if (fast_tail && g_gemm_fast_tail >= 2 && !g_gemm_skip_tail && rem * sc.slices * 4 <= CUS && !g_gemm_wide)
       sc.tail_items = (g_gemm_fast_tail == 3 ? -1 : 1) * rem * sc.slices * 4;
-    launch_prefetch<T, Epi>(g, epi, sc, st);
+    if (g_gemm_wide) launch_wide<T, Epi>(g, epi, sc, st, g_wide_diag);
+    else launch_prefetch<T, Epi>(g, epi, sc, st);
     if (rem > 0 && !g_gemm_skip_tail) {
       PersistSched tail = sc;
       tail.nblk_full = 0;           // no whole tiles for anybody: K-slice items or quadrant items only

@@ -21,6 +21,8 @@ def both(fn):
     outs = []
     for algo in (4, 5):
         call("cogaim_set_gemm_algo", algo)
+        if algo == 5 and os.environ.get("WIDE"):          # the four-wave kernel in place of gemm256f_kernel
+            call("cogaim_set_gemm_algo", 13)
         outs.append(fn())
         torch.cuda.synchronize()
     return outs
