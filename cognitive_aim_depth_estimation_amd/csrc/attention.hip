@@ -191,11 +191,14 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
       const float alpha = __builtin_amdgcn_exp2f(-d);
       m_run += d;
       l_run *= alpha;
+      const float nm = -m_run;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         o[0][i] *= alpha; o[1][i] *= alpha;
         s[0][i] -= d; s[1][i] -= d;
-        negm[i] = -m_run;
+        // written in place (tied operand): as a plain assignment the new values get registers of their own and the
+        // common path, which does not rescale, pays sixteen copies per tile to follow them
+        asm volatile("v_mov_b32 %0, %1" : "+v"(negm[i]) : "v"(nm));
       }
     }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
