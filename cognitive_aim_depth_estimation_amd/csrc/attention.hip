@@ -126,12 +126,29 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
   __syncthreads();
   // One key tile.  The buffer index is a compile-time constant (the loop below alternates two copies of this body), so
   // every LDS address of the tile is a loop-invariant register plus an immediate offset.
-  auto tile = [&](const int t, auto buf_c) __attribute__((always_inline)) {
-    constexpr int BUF = decltype(buf_c)::value;
+  // A wave whose 32 queries all lie past the sequence end (the last query block's upper waves) has nothing to compute:
+  // it stages its share of every tile, meets the barriers, and leaves its SIMD to the co-resident workgroups.
+  if (__builtin_amdgcn_readfirstlane(q0) >= Tn) {
+    for (int t = 0; t + 1 < nt; ++t) {
+      const int nb = (t & 1) ^ 1;
+      if (t + 2 < nt) LOAD_TILE_INSIDE(nb) else LOAD_TILE((t + 1) * KV, nb);
+      TILE_LANDED();
+      __syncthreads();
+    }
+    return;
+  }
+  // LAST: the sequence's last tile (keys past the end are masked, nothing is staged behind it, no barrier after it);
+  // NKB: how many of its two 32-key halves hold keys at all.  A half of nothing but padding contributes exact
+  // zeros to the row sums and to O, so leaving it out changes no bit of the result.
+  auto tile = [&](const int t, auto buf_c, auto last_c, auto nkb_c) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_c)::value, NKB = decltype(nkb_c)::value;
+    constexpr bool LAST = decltype(last_c)::value != 0;
     const int kv0 = t * KV;
     // the next tile goes straight into the other buffer (last read one iteration ago, before the barrier)
-    if (t + 2 < nt) LOAD_TILE_INSIDE(BUF ^ 1)       // only the last tile can reach past the sequence end
-    else if (t + 1 < nt) LOAD_TILE(kv0 + KV, BUF ^ 1);
+    if constexpr (!LAST) {
+      if (t + 2 < nt) LOAD_TILE_INSIDE(BUF ^ 1)     // only the last tile can reach past the sequence end
+      else LOAD_TILE(kv0 + KV, BUF ^ 1);
+    }
     const char* ks = smem + BUF * K_TILE;
     const char* vs = smem + (2 + BUF) * K_TILE;
 
@@ -139,10 +156,10 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
     // to the running maximum (the accumulator starts at -m_run, so no subtraction pass is needed)
     // All eight K fragments are requested before the first MFMA and the two accumulator chains alternate: left to
     // itself the compiler reads one fragment, waits for it, and issues one MFMA that depends on the previous one.
-    f32x16 s[2];
-    v8 kf[2][4];
+    f32x16 s[NKB];
+    v8 kf[NKB][4];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb) {
       const int r = kb * 32 + ql;
       const int sw = (r >> 1) & 7;
 #pragma unroll
@@ -150,30 +167,39 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
         kf[kb][s4] = *reinterpret_cast<const v8*>(ks + r * 128 + (((2 * s4 + hh) ^ sw) << 4));
     }
     __builtin_amdgcn_sched_barrier(0);
-    s[0] = Hf::mfma32(kf[0][0], qf[0], negm);                             // negm: 16 registers holding -m_run
-    s[1] = Hf::mfma32(kf[1][0], qf[0], negm);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) s[kb] = Hf::mfma32(kf[kb][0], qf[0], negm);     // negm: 16 registers holding -m_run
 #pragma unroll
     for (int s4 = 1; s4 < 4; ++s4)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) s[kb] = Hf::mfma32(kf[kb][s4], qf[s4], s[kb]);
+      for (int kb = 0; kb < NKB; ++kb) s[kb] = Hf::mfma32(kf[kb][s4], qf[s4], s[kb]);
     __builtin_amdgcn_sched_barrier(0);
-    if (kv0 + KV > Tn) {   // mask keys past the sequence end (last tile only)
+    if constexpr (LAST) {
+      if (kv0 + KV > Tn) {   // mask keys past the sequence end
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (key >= Tn) s[kb][i] = -INFINITY;
-        }
+          for (int i = 0; i < 16; ++i) {
+            const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            if (key >= Tn) s[kb][i] = -INFINITY;
+          }
+      }
     }
     // tile maximum per query column (lane-local + one half swap), relative to m_run
     float mx;
     {   // four independent chains (a single 31-deep dependent chain of v_max would serialise the wave)
       float m4[4];
+      if constexpr (NKB == 2) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) m4[c] = fmaxf(s[0][c], s[1][c]);
+        for (int c = 0; c < 4; ++c) m4[c] = fmaxf(s[0][c], s[1][c]);
 #pragma unroll
-      for (int i = 4; i < 16; ++i) m4[i & 3] = fmaxf(fmaxf(m4[i & 3], s[0][i]), s[1][i]);      // v_max3_f32
+        for (int i = 4; i < 16; ++i) m4[i & 3] = fmaxf(fmaxf(m4[i & 3], s[0][i]), s[1][i]);      // v_max3_f32
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m4[c] = s[0][c];
+#pragma unroll
+        for (int i = 4; i < 16; ++i) m4[i & 3] = fmaxf(m4[i & 3], s[0][i]);
+      }
       mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
     }
     {
@@ -195,7 +221,8 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         o[0][i] *= alpha; o[1][i] *= alpha;
-        s[0][i] -= d; s[1][i] -= d;
+        s[0][i] -= d;
+        if constexpr (NKB == 2) s[1][i] -= d;
         // written in place (tied operand): as a plain assignment the new values get registers of their own and the
         // common path, which does not rescale, pays sixteen copies per tile to follow them
         asm volatile("v_mov_b32 %0, %1" : "+v"(negm[i]) : "v"(nm));
@@ -204,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 l2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};        // two v_pk_add_f32 chains: 16 adds for the 32 values
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
         s[kb][i] = __builtin_amdgcn_exp2f(s[kb][i]);
@@ -245,21 +272,39 @@ __global__ __launch_bounds__(256, 2) void mhsa_qkv_kernel(const T* __restrict__ 
     }
     V_READ(0); V_READ(1);
     V_WAIT(0, 4); PV(0);
-    V_READ(2);
-    V_WAIT(1, 4); PV(1);
-    V_READ(3);
-    V_WAIT(2, 4); PV(2);
-    V_WAIT(3, 0); PV(3);
+    if constexpr (NKB == 2) {
+      V_READ(2);
+      V_WAIT(1, 4); PV(1);
+      V_READ(3);
+      V_WAIT(2, 4); PV(2);
+      V_WAIT(3, 0); PV(3);
+    } else {
+      V_WAIT(1, 0); PV(1);
+    }
 #undef V_READ
 #undef V_WAIT
 #undef PV
 
-    TILE_LANDED();
-    __syncthreads();
+    if constexpr (!LAST) {
+      TILE_LANDED();
+      __syncthreads();
+    }
   };
-  for (int t = 0; t < nt; t += 2) {
-    tile(t, std::integral_constant<int, 0>{});
-    if (t + 1 < nt) tile(t + 1, std::integral_constant<int, 1>{});
+  using std::integral_constant;
+  for (int t = 0; t + 1 < nt; t += 2) {
+    tile(t, integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, 2>{});
+    if (t + 2 < nt) tile(t + 1, integral_constant<int, 1>{}, integral_constant<int, 0>{}, integral_constant<int, 2>{});
+  }
+  {
+    const int t = nt - 1;
+    const bool one_half = t * KV + 32 >= Tn;            // the tile's second 32 keys are all past the end
+    if (t & 1) {
+      if (one_half) tile(t, integral_constant<int, 1>{}, integral_constant<int, 1>{}, integral_constant<int, 1>{});
+      else tile(t, integral_constant<int, 1>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{});
+    } else {
+      if (one_half) tile(t, integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 1>{});
+      else tile(t, integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{});
+    }
   }
 
   // combine the two lane halves' partial sums, normalise, store ctx[b*T+q][h*64 + d]

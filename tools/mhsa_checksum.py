@@ -7,7 +7,7 @@ from cognitive_aim_depth_estimation_amd._lib import call, ptr, stream_ptr
 LOG2E = 1.4426950408889634
 torch.manual_seed(0)
 for dt, tdt in ((0, torch.bfloat16), (1, torch.float16)):
-    for (B, T, H) in ((2, 17, 12), (2, 26, 12), (2, 257, 12), (2, 1370, 12)):
+    for (B, T, H) in ((2, 17, 12), (2, 26, 12), (2, 100, 12), (2, 128, 12), (2, 257, 12), (2, 1370, 12), (1, 5477, 12)):
         D = 64 * H
         q, k, v = (torch.randn(B, T, H, 64, device="cuda") for _ in range(3))
         q = q * 2.0
