@@ -178,7 +178,8 @@ def test_layernorm(out, M, D):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("B,T,H", [(2, 17, 2), (1, 64, 1), (2, 257, 3), (2, 1370, 12), (1, 130, 2)])
+@pytest.mark.parametrize("B,T,H", [(2, 17, 2), (1, 64, 1), (2, 257, 3), (2, 1370, 12), (1, 130, 2),
+                                   (1, 1, 1), (1, 48, 1), (2, 100, 2), (1, 193, 2), (1, 128, 1)])   # last key tile whole / masked / half, alone or not
 def test_mhsa_qkv(dtype, B, T, H):
     """Fused-buffer attention (V read row-major through the LDS transpose read)."""
     di, tdt = DT[dtype]
