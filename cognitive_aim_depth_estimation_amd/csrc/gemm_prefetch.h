@@ -264,9 +264,19 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(GemmShape g, Epi epi, 
   float peak = 0.f;           // fp16 range guard of the 16-bit epilogues (see track_peak)
   for (int j = 0; j < n_items; ++j) {
     if (j) item_rs(j + 1, na_lo, na_hi, na_n, nw_lo, nw_hi, nw_n);   // the cursor is inside tile j until its last K-tiles
+    // (stamps builds: the 100-MHz clock at the start of a tile, after its first K-tile, after its last one and after
+    // the epilogue was issued, taken by wave 0 -- tools/gemm_stamps.py)
+#ifdef COGAIM_STAMPS
+#define F_STAMP(k_) if (tid == 0 && j < 12) g_stamp_buf[(blockIdx.x * 12 + j) * 4 + (k_)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define F_STAMP(k_)
+#endif
+    F_STAMP(0);
     F_KT(1, 0);
+    F_STAMP(1);
     for (int kt = 2; kt < nk; ++kt) F_KT(0, 0);
     F_KT(0, 1);
+    F_STAMP(2);
 
     // ---- epilogue (that of gemm256p_kernel) ------------------------------------------------------------------
     int z, row0, col0;
@@ -368,6 +378,8 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(GemmShape g, Epi epi, 
         }
       }
     }
+    F_STAMP(3);
+#undef F_STAMP
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
